@@ -1,0 +1,206 @@
+/*
+ * rtamd.h -- C ABI of the MI355X (gfx950) render path.
+ *
+ * The reference (joshuabenuck/ray-tracer, Rust) has no FFI or plugin interface; its de-facto
+ * boundary for the per-pixel render loop is one method,
+ *     pub fn render(&self, world: &mut World) -> Canvas        (src/scene.rs:236-248)
+ * with inputs Camera {hsize, vsize, field_of_view, transform, pixel_size, half_width,
+ * half_height} (src/scene.rs:171-179), World {objects, lights} (src/scene.rs:6-9) and output
+ * Canvas {width, height, pixels: Vec<Color>} (src/tuple.rs:309-313).  This header is what a
+ * Rust `extern "C"` block (or any other host) binds instead: the host flattens World + Camera
+ * once into the plain-old-data `rtamd_scene` below, uploads it, and asks for pixels.
+ *
+ * Conventions: every pointer in `rtamd_scene` is host memory owned by the caller and is copied
+ * by rtamd_scene_upload; functions return 0 or a negative RTAMD_E_* code and never unwind or
+ * abort across the boundary (the reference panics on a singular transform, src/shape.rs:40 --
+ * here the flattening host reports it before upload); calls are blocking unless stated; one
+ * context drives one GPU, distinct contexts are independent.
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTAMD_OK 0
+#define RTAMD_E_INVALID -1   /* bad argument or malformed scene (message in rtamd_last_error) */
+#define RTAMD_E_HIP -2       /* a HIP runtime call failed */
+#define RTAMD_E_NO_SCENE -3  /* render requested before a scene was uploaded */
+#define RTAMD_E_LIMIT -4     /* scene exceeds a documented limit of the device path */
+#define RTAMD_E_OVERFLOW -5  /* a per-lane CSG intersection list overflowed during the last render */
+
+/* Leaf kinds (src/shapes/{sphere,plane,cube,cylinder,cone,triangle}.rs). A MESH leaf is a run of
+ * consecutive (DFS order) triangles that share transform chain, material, shadow flag and
+ * flat/smooth kind; every triangle of it keeps its own place in the DFS order. */
+enum { RTAMD_SPHERE = 0, RTAMD_PLANE = 1, RTAMD_CUBE = 2, RTAMD_CYLINDER = 3, RTAMD_CONE = 4, RTAMD_MESH = 5 };
+/* Pattern kinds (src/pattern.rs:4-10). */
+enum { RTAMD_PAT_NONE = 0, RTAMD_PAT_STRIPE, RTAMD_PAT_GRADIENT, RTAMD_PAT_RING, RTAMD_PAT_CHECKERS, RTAMD_PAT_TEST };
+/* CSG operations (src/shapes/csg.rs:5-9). */
+enum { RTAMD_CSG_UNION = 0, RTAMD_CSG_INTERSECTION = 1, RTAMD_CSG_DIFFERENCE = 2 };
+
+#define RTAMD_LEAF_CLOSED 1u  /* cylinder/cone `closed` */
+#define RTAMD_LEAF_SHADOW 2u  /* Props::shadow (src/shape.rs:9): leaf takes part in is_shadowed */
+#define RTAMD_LEAF_SMOOTH 4u  /* MESH of Normal::Smooth triangles (src/shapes/triangle.rs:5-8) */
+
+#define RTAMD_MAX_LIGHTS 16
+#define RTAMD_MAX_CHAIN 8           /* transform levels (ancestors + own) of one leaf */
+#define RTAMD_MAX_CSG_LEAVES 64     /* leaves below one top-most CSG node */
+#define RTAMD_CSG_LIST_CAP 24       /* per-lane intersection list of one top-most CSG node */
+#define RTAMD_MAX_REMAINING 8       /* recursion budget supported (the reference renders with 4) */
+
+/* One primitive leaf, in depth-first order of the object tree (= the order in which the
+ * reference's stable sorts keep intersections of equal t, src/scene.rs:19-26,
+ * src/shapes/group.rs:37-45). 144 bytes. */
+typedef struct rtamd_leaf {
+    double w2o[12];      /* rows 0..2 of inverse(own) * inverse(parent_n) * ... * inverse(parent_1):
+                            world ray -> object ray (src/shape.rs:39-42 applied through every group
+                            and CSG level; the direction is not re-normalised, so t is world-scale) */
+    double p0, p1;       /* cylinder/cone min, max (src/shapes/cylinder.rs:6-11) */
+    int32_t kind;        /* RTAMD_SPHERE ... RTAMD_MESH */
+    uint32_t flags;      /* RTAMD_LEAF_* */
+    int32_t material;    /* index into materials (after Group::refresh_parents inheritance) */
+    int32_t eq_class;    /* id of the first leaf (DFS order) that is value-equal to this one under
+                            `PartialEq for dyn Shape` (src/shape.rs:23-27,119-123) */
+    int32_t chain_start; /* first of chain_len 3x4 matrices in `chain`: inverse of each entry of the
+                            leaf's parent_transforms (root first), then inverse of its own transform
+                            (src/shape.rs:49-70). Leaves below a CSG node have only their own. */
+    int32_t chain_len;
+    int32_t tri_start;   /* MESH: first triangle in tri_geom / tri_normals */
+    int32_t tri_count;   /* MESH: number of triangles; 0 otherwise */
+} rtamd_leaf;
+
+/* 232 bytes. */
+typedef struct rtamd_material {
+    double color[3];
+    double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    double pat_a[3], pat_b[3];
+    double pat_inv[12]; /* rows 0..2 of inverse(pattern.transform) (src/pattern.rs:57-61) */
+    int32_t pattern_kind;
+    int32_t pad_;
+} rtamd_material;
+
+/* One CSG node of a top-most CSG object, nodes in post-order. Leaves of the left child are
+ * [leaf_lo, leaf_mid), of the right child [leaf_mid, leaf_hi) (global leaf indices).
+ * Bit (leaf - leaf_lo) of left_mask says `left.includes(leaf)` (src/shapes/csg.rs:64), which by
+ * value equality can also be true for a leaf of the right child. */
+typedef struct rtamd_csg_node {
+    uint64_t left_mask;
+    int32_t op;
+    int32_t leaf_lo, leaf_mid, leaf_hi;
+    int32_t pad_;
+} rtamd_csg_node;
+
+/* A top-most CSG object: csg_nodes[node_start .. node_start+node_count) and leaves [leaf_lo, leaf_hi). */
+typedef struct rtamd_csg_root {
+    int32_t node_start, node_count;
+    int32_t leaf_lo, leaf_hi;
+} rtamd_csg_root;
+
+#define RTAMD_VISIT_CSG 1u        /* unit indexes csg_roots, else leaves */
+#define RTAMD_VISIT_FIRST 2u      /* first visit of this unit: the only one closest-hit and shadow rays use */
+#define RTAMD_VISIT_CLASS_END 4u  /* last visit of its equality class */
+
+/* Traversal order of the device: units grouped by equality class (the n1/n2 container walk of
+ * src/intersection.rs:85-112 is evaluated per class). A plain leaf appears once; a CSG root
+ * appears once per class present among its leaves. */
+typedef struct rtamd_visit {
+    int32_t unit;
+    int32_t eq_class;
+    uint32_t flags;
+    int32_t class_material; /* material of the class (refractive index source) */
+} rtamd_visit;
+
+typedef struct rtamd_camera {
+    int32_t hsize, vsize;
+    double pixel_size, half_width, half_height; /* Camera::new, src/scene.rs:182-209 */
+    double inv[12];                             /* rows 0..2 of inverse(camera.transform) */
+} rtamd_camera;
+
+typedef struct rtamd_light {
+    double position[3];
+    double intensity[3];
+} rtamd_light;
+
+typedef struct rtamd_scene {
+    rtamd_camera camera;
+    int32_t max_remaining; /* 4 in the reference (src/scene.rs:243) */
+    int32_t n_lights;
+    const rtamd_light* lights;
+    int32_t n_leaves;
+    const rtamd_leaf* leaves;
+    int32_t n_chain;
+    const double* chain; /* n_chain x 12 */
+    int32_t n_tris;
+    const double* tri_geom;    /* n_tris x 9: p1, e1 = p2-p1, e2 = p3-p1 (src/shapes/triangle.rs:22-49) */
+    const double* tri_normals; /* n_tris x 9: flat: normal,0,0 ; smooth: n1, n2, n3 */
+    int32_t n_materials;
+    const rtamd_material* materials;
+    int32_t n_csg_nodes;
+    const rtamd_csg_node* csg_nodes;
+    int32_t n_csg_roots;
+    const rtamd_csg_root* csg_roots;
+    int32_t n_visits;
+    const rtamd_visit* visits;
+    int32_t n_classes;
+} rtamd_scene;
+
+/* Which rows of the frame a render call produces: rows are cut into tiles of `tile_rows`
+ * consecutive rows, tile i belongs to part (i % n_parts); this call renders part `part`.
+ * Output is compact: the part's rows in increasing order, hsize pixels each.
+ * {tile_rows, 0, 1} = the whole frame. */
+typedef struct rtamd_rows {
+    int32_t tile_rows, part, n_parts;
+} rtamd_rows;
+
+#define RTAMD_MODE_STRICT 0 /* no fused multiply-add, IEEE divide: the reference's f64 evaluation order */
+#define RTAMD_MODE_FAST 1   /* contraction to FMA and reciprocal-multiply allowed (results differ in the last bits) */
+
+typedef struct rtamd_stats {
+    uint64_t rays;          /* World::intersect-equivalent traversals executed (primary, reflection,
+                               refraction, shadow, and the n1/n2 container pass) */
+    uint64_t primary_rays, shadow_rays, reflect_rays, refract_rays, container_passes;
+    uint64_t shade_points;  /* shade_hit-equivalents */
+    uint64_t light_samples; /* lighting() evaluations */
+    uint64_t csg_overflows; /* lanes whose CSG list overflowed (results then invalid) */
+    double kernel_ms;       /* duration of the last render kernel, from HIP events on its stream */
+} rtamd_stats;
+
+typedef struct rtamd_ctx rtamd_ctx;
+
+/* Library / device. Replaces nothing in the reference (it has no device). */
+int rtamd_ctx_create(int device, rtamd_ctx** out);
+void rtamd_ctx_destroy(rtamd_ctx* ctx);
+const char* rtamd_last_error(const rtamd_ctx* ctx); /* ctx may be NULL: creation errors */
+
+/* Replaces the scene state Camera::render reads (World after refresh_parents, Camera):
+ * src/scene.rs:236-238. Validates indices and limits; copies to the device. */
+int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* scene);
+
+/* Number of rows / pixels a rows-spec selects for the uploaded scene. */
+int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows);
+
+/* Replaces the pixel loop of Camera::render (src/scene.rs:240-246) for the selected rows:
+ * ray_for_pixel + color_at(ray, max_remaining) + Canvas::write_pixel.
+ * d_rgb: device pointer, 3 doubles per pixel (Canvas.pixels, src/tuple.rs:309-313), may be NULL;
+ * d_rgb8: device pointer, 3 bytes per pixel quantised as `From<Color> for (usize,usize,usize)`
+ * (src/tuple.rs:226-237), may be NULL. Asynchronous on `stream` (a hipStream_t, NULL = default). */
+int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream);
+
+/* Camera::render for the whole frame into host memory (either pointer may be NULL). Blocking. */
+int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8);
+
+/* World::color_at(ray, remaining) (src/scene.rs:53-63) for n caller-supplied rays:
+ * h_rays = n x 6 doubles (origin xyz, direction xyz), h_rgb = n x 3 doubles. Blocking. */
+int rtamd_color_at(rtamd_ctx* ctx, int mode, const double* h_rays, int64_t n, int remaining, double* h_rgb);
+
+/* Counters accumulated since the last reset (waits for the stream of the last render). */
+int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out);
+int rtamd_reset_stats(rtamd_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

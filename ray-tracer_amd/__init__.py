@@ -1,0 +1,283 @@
+"""ctypes bindings of the MI355X render path.
+
+Two in-tree shared libraries (built by ``ray-tracer_amd/Makefile``; see ``__graft_entry__.build``):
+
+* ``lib/librtamd.so``       -- the GPU library, C ABI of ``include/rtamd.h`` (hand-written HIP, gfx950)
+* ``lib/librtamd_host.so``  -- the host-side scene API (C++ mirror of the reference's World/Camera/
+  shapes/loaders) that flattens a scene into an ``rtamd_scene``
+
+Import with ``importlib.import_module("ray-tracer_amd")`` (the directory name is not an
+identifier).  There is no CPU fallback: without the libraries the import raises, without a GPU
+``Context()`` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+MODE_STRICT = 0
+MODE_FAST = 1
+
+
+class RtamdError(RuntimeError):
+    pass
+
+
+def _load(name):
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `make -C {_HERE}` (hipcc, --offload-arch=gfx950)")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_gpu = _load("librtamd.so")
+_host = _load("librtamd_host.so")
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "primary_rays", "shadow_rays", "reflect_rays", "refract_rays",
+                                          "container_passes", "shade_points", "light_samples", "csg_overflows")] + \
+               [("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Rows(C.Structure):
+    _fields_ = [("tile_rows", C.c_int32), ("part", C.c_int32), ("n_parts", C.c_int32)]
+
+
+# every symbol include/rtamd.h declares
+GPU_SYMBOLS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error", "rtamd_scene_upload", "rtamd_part_rows",
+               "rtamd_render_rows", "rtamd_render", "rtamd_color_at", "rtamd_get_stats", "rtamd_reset_stats"]
+
+_gpu.rtamd_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+_gpu.rtamd_ctx_create.restype = C.c_int
+_gpu.rtamd_ctx_destroy.argtypes = [C.c_void_p]
+_gpu.rtamd_ctx_destroy.restype = None
+_gpu.rtamd_last_error.argtypes = [C.c_void_p]
+_gpu.rtamd_last_error.restype = C.c_char_p
+_gpu.rtamd_scene_upload.argtypes = [C.c_void_p, C.c_void_p]
+_gpu.rtamd_scene_upload.restype = C.c_int
+_gpu.rtamd_part_rows.argtypes = [C.c_void_p, C.POINTER(Rows)]
+_gpu.rtamd_part_rows.restype = C.c_int64
+_gpu.rtamd_render_rows.argtypes = [C.c_void_p, C.POINTER(Rows), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+_gpu.rtamd_render_rows.restype = C.c_int
+_gpu.rtamd_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+_gpu.rtamd_render.restype = C.c_int
+_gpu.rtamd_color_at.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+_gpu.rtamd_color_at.restype = C.c_int
+_gpu.rtamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+_gpu.rtamd_get_stats.restype = C.c_int
+_gpu.rtamd_reset_stats.argtypes = [C.c_void_p]
+_gpu.rtamd_reset_stats.restype = C.c_int
+
+_host.rth_last_error.restype = C.c_char_p
+for _n in ("rth_load_yaml", "rth_load_yaml_str", "rth_load_sg"):
+    getattr(_host, _n).argtypes = [C.c_char_p]
+    getattr(_host, _n).restype = C.c_void_p
+_host.rth_builtin_scene.argtypes = [C.c_char_p, C.c_char_p]
+_host.rth_builtin_scene.restype = C.c_void_p
+_host.rth_save_sg.argtypes = [C.c_void_p, C.c_char_p]
+_host.rth_free_scene.argtypes = [C.c_void_p]
+_host.rth_free_scene.restype = None
+_host.rth_scene_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+_host.rth_set_resolution.argtypes = [C.c_void_p, C.c_int, C.c_int]
+_host.rth_flatten.argtypes = [C.c_void_p, C.c_int]
+_host.rth_flatten.restype = C.c_void_p
+_host.rth_flat_view.argtypes = [C.c_void_p]
+_host.rth_flat_view.restype = C.c_void_p
+_host.rth_free_flat.argtypes = [C.c_void_p]
+_host.rth_free_flat.restype = None
+_host.rth_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+_host.rth_canvas_save.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+_host.rth_canvas_quantize.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+_host.rth_canvas_ppm.argtypes = [C.c_void_p, C.c_int, C.c_int]
+_host.rth_canvas_ppm.restype = C.c_void_p
+_host.rth_free_str.argtypes = [C.c_void_p]
+_host.rth_free_str.restype = None
+_host.rth_obj_info.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 7
+_host.rth_obj_triangle.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+
+
+def _host_err():
+    return RtamdError(_host.rth_last_error().decode())
+
+
+class Flat:
+    """A flattened scene (owns the arrays an ``rtamd_scene`` points into)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @property
+    def view(self):
+        return _host.rth_flat_view(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _host.rth_free_flat(self._h)
+            self._h = None
+
+
+class Scene:
+    """World + Camera of the host API."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise _host_err()
+        self._h = handle
+
+    @staticmethod
+    def from_yaml(path):
+        return Scene(_host.rth_load_yaml(os.fsencode(path)))
+
+    @staticmethod
+    def from_yaml_str(text):
+        return Scene(_host.rth_load_yaml_str(text.encode()))
+
+    @staticmethod
+    def from_sg(path):
+        return Scene(_host.rth_load_sg(os.fsencode(path)))
+
+    @staticmethod
+    def builtin(name, arg=None):
+        return Scene(_host.rth_builtin_scene(name.encode(), os.fsencode(arg) if arg else None))
+
+    def info(self):
+        v = [C.c_int() for _ in range(4)]
+        if _host.rth_scene_info(self._h, *[C.byref(x) for x in v]):
+            raise _host_err()
+        return dict(hsize=v[0].value, vsize=v[1].value, n_objects=v[2].value, n_lights=v[3].value)
+
+    def set_resolution(self, hsize, vsize):
+        if _host.rth_set_resolution(self._h, hsize, vsize):
+            raise _host_err()
+        return self
+
+    def save_sg(self, path):
+        if _host.rth_save_sg(self._h, os.fsencode(path)):
+            raise _host_err()
+
+    def flatten(self, max_remaining=4):
+        h = _host.rth_flatten(self._h, max_remaining)
+        if not h:
+            raise _host_err()
+        return Flat(h)
+
+    def render(self, mode=MODE_FAST, want_u8=False):
+        """Camera::render on the GPU -> (vsize, hsize, 3) float64 [, uint8], Stats."""
+        i = self.info()
+        rgb = np.empty((i["vsize"], i["hsize"], 3), dtype=np.float64)
+        u8 = np.empty((i["vsize"], i["hsize"], 3), dtype=np.uint8) if want_u8 else None
+        st = Stats()
+        if _host.rth_render(self._h, mode, rgb.ctypes.data, u8.ctypes.data if want_u8 else None, C.byref(st)):
+            raise _host_err()
+        return (rgb, u8, st) if want_u8 else (rgb, st)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _host.rth_free_scene(self._h)
+            self._h = None
+
+
+class Context:
+    """One GPU (``rtamd_ctx``)."""
+
+    def __init__(self, device=0):
+        p = C.c_void_p()
+        rc = _gpu.rtamd_ctx_create(device, C.byref(p))
+        if rc:
+            raise RtamdError(f"rtamd_ctx_create({device}) = {rc}: {_gpu.rtamd_last_error(None).decode()}")
+        self._h = p
+        self._flat = None
+
+    def _chk(self, rc):
+        if rc:
+            raise RtamdError(f"rtamd error {rc}: {_gpu.rtamd_last_error(self._h).decode()}")
+
+    def upload(self, flat):
+        self._chk(_gpu.rtamd_scene_upload(self._h, flat.view))
+        self._flat = flat
+        return self
+
+    def part_rows(self, tile_rows, part, n_parts):
+        r = Rows(tile_rows, part, n_parts)
+        return _gpu.rtamd_part_rows(self._h, C.byref(r))
+
+    def render_rows(self, tile_rows, part, n_parts, mode, d_rgb=0, d_rgb8=0, stream=0):
+        """Asynchronous; d_rgb / d_rgb8 are device addresses (e.g. ``tensor.data_ptr()``)."""
+        r = Rows(tile_rows, part, n_parts)
+        self._chk(_gpu.rtamd_render_rows(self._h, C.byref(r), mode, C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None),
+                                         C.c_void_p(stream or None)))
+
+    def render(self, hsize, vsize, mode=MODE_FAST, want_u8=False):
+        rgb = np.empty((vsize, hsize, 3), dtype=np.float64)
+        u8 = np.empty((vsize, hsize, 3), dtype=np.uint8) if want_u8 else None
+        self._chk(_gpu.rtamd_render(self._h, mode, rgb.ctypes.data, u8.ctypes.data if want_u8 else None))
+        return (rgb, u8) if want_u8 else rgb
+
+    def color_at(self, rays, remaining, mode=MODE_STRICT):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.empty((rays.shape[0], 3), dtype=np.float64)
+        self._chk(_gpu.rtamd_color_at(self._h, mode, rays.ctypes.data, rays.shape[0], remaining, out.ctypes.data))
+        return out
+
+    def stats(self):
+        st = Stats()
+        self._chk(_gpu.rtamd_get_stats(self._h, C.byref(st)))
+        return st
+
+    def reset_stats(self):
+        self._chk(_gpu.rtamd_reset_stats(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _gpu.rtamd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def quantize(rgb):
+    """`From<Color> for (usize, usize, usize)` of the reference (src/tuple.rs:226-237) on an array."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    out = np.empty(rgb.shape, dtype=np.uint8)
+    _host.rth_canvas_quantize(rgb.ctypes.data, rgb.size // 3, out.ctypes.data)
+    return out
+
+
+def canvas_to_ppm(rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    p = _host.rth_canvas_ppm(rgb.ctypes.data, rgb.shape[1], rgb.shape[0])
+    if not p:
+        raise _host_err()
+    s = C.string_at(p).decode()
+    _host.rth_free_str(p)
+    return s
+
+
+def canvas_save(rgb, path, ppm=False):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    if _host.rth_canvas_save(rgb.ctypes.data, rgb.shape[1], rgb.shape[0], os.fsencode(path), 1 if ppm else 0):
+        raise _host_err()
+
+
+def obj_info(text):
+    v = [C.c_int() for _ in range(7)]
+    if _host.rth_obj_info(text.encode(), *[C.byref(x) for x in v]):
+        raise _host_err()
+    k = ("n_vertices", "n_normals", "n_default_tris", "n_groups", "n_group_tris", "lines_ignored", "n_smooth")
+    return dict(zip(k, [x.value for x in v]))
+
+
+def obj_triangle(text, k):
+    out = np.zeros(21)
+    smooth = _host.rth_obj_triangle(text.encode(), k, out.ctypes.data)
+    if smooth < 0:
+        raise _host_err()
+    return dict(smooth=bool(smooth), p=out[:9].reshape(3, 3), n=out[9:].reshape(3, 4))

@@ -1,0 +1,369 @@
+// Host side of the GPU library: the C ABI of include/rtamd.h.
+// Owns the device copies of a flattened scene and the scratch the render kernel needs
+// (pixel queue head, counters, per-lane shade-point frames); launches the kernel of the
+// requested arithmetic mode on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rtamd_device.h"
+
+static_assert(sizeof(rtamd_leaf) == 144, "rtamd_leaf layout");
+static_assert(sizeof(DLeaf) == 160, "DLeaf layout");
+static_assert(sizeof(rtamd_material) == 232, "rtamd_material layout");
+static_assert(sizeof(rtamd_visit) == 16, "rtamd_visit layout");
+
+struct rtamd_ctx {
+    int device = 0;
+    int num_cus = 0;
+    std::string err;
+    bool have_scene = false, has_csg = false;
+    DScene ds{};
+    std::vector<void*> scene_bufs;
+    unsigned long long* d_queue = nullptr;
+    unsigned long long* d_stats = nullptr;
+    double* d_frames = nullptr;
+    size_t frames_levels = 0;
+    int64_t total_lanes = 0;
+    int max_blocks[2][2] = {{0, 0}, {0, 0}};  // [mode][has_csg]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+static std::string g_create_err;
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return RTAMD_E_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+static int fail(rtamd_ctx* ctx, int code, const std::string& msg) {
+    ctx->err = msg;
+    return code;
+}
+
+// The functions below are declared extern "C" in include/rtamd.h.
+
+const char* rtamd_last_error(const rtamd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int rtamd_ctx_create(int device, rtamd_ctx** out) {
+    if (!out) {
+        g_create_err = "rtamd_ctx_create: out is NULL";
+        return RTAMD_E_INVALID;
+    }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        g_create_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return RTAMD_E_HIP;
+    }
+    if (device < 0 || device >= n) {
+        g_create_err = "device index out of range";
+        return RTAMD_E_INVALID;
+    }
+    auto* ctx = new rtamd_ctx();
+    ctx->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_err = std::string(what) + ": " + hipGetErrorString(err);
+        delete ctx;
+        return RTAMD_E_HIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->num_cus = prop.multiProcessorCount;
+    for (int csg = 0; csg < 2; csg++) {
+        int b = 0;
+        if ((e = rtamd_occupancy_strict(csg != 0, &b)) != hipSuccess) return bail("occupancy(strict)", e);
+        ctx->max_blocks[RTAMD_MODE_STRICT][csg] = std::max(1, b) * ctx->num_cus;
+        if ((e = rtamd_occupancy_fast(csg != 0, &b)) != hipSuccess) return bail("occupancy(fast)", e);
+        ctx->max_blocks[RTAMD_MODE_FAST][csg] = std::max(1, b) * ctx->num_cus;
+    }
+    int mb = 0;
+    for (int m = 0; m < 2; m++)
+        for (int c = 0; c < 2; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
+    ctx->total_lanes = (int64_t)mb * 256;
+    if ((e = hipMalloc(&ctx->d_queue, 256)) != hipSuccess) return bail("hipMalloc(queue)", e);
+    if ((e = hipMalloc(&ctx->d_stats, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stats)", e);
+    if ((e = hipMemset(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    *out = ctx;
+    return RTAMD_OK;
+}
+
+static void free_scene(rtamd_ctx* ctx) {
+    for (void* p : ctx->scene_bufs) (void)hipFree(p);
+    ctx->scene_bufs.clear();
+    ctx->have_scene = false;
+}
+
+void rtamd_ctx_destroy(rtamd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_scene(ctx);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+template <class T>
+static int upload(rtamd_ctx* ctx, const T* src, size_t n, const T** dst) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(ctx, hipMalloc(&p, bytes));
+    ctx->scene_bufs.push_back(p);
+    if (n) HIPCHK(ctx, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T*)p;
+    return RTAMD_OK;
+}
+
+static int ensure_frames(rtamd_ctx* ctx, int levels) {
+    if ((size_t)levels <= ctx->frames_levels) return RTAMD_OK;
+    if (ctx->d_frames) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        HIPCHK(ctx, hipFree(ctx->d_frames));
+        ctx->d_frames = nullptr;
+        ctx->frames_levels = 0;
+    }
+    size_t bytes = (size_t)levels * RTAMD_FRAME_F64 * (size_t)ctx->total_lanes * sizeof(double);
+    HIPCHK(ctx, hipMalloc(&ctx->d_frames, bytes));
+    ctx->frames_levels = (size_t)levels;
+    return RTAMD_OK;
+}
+
+int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
+    if (!ctx || !s) return RTAMD_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // ---- validation: every index the kernel follows is checked here
+    if (s->camera.hsize <= 0 || s->camera.vsize <= 0) return fail(ctx, RTAMD_E_INVALID, "camera size must be positive");
+    if (s->max_remaining < 0 || s->max_remaining > RTAMD_MAX_REMAINING) return fail(ctx, RTAMD_E_LIMIT, "max_remaining out of range");
+    if (s->n_lights < 0 || s->n_lights > RTAMD_MAX_LIGHTS) return fail(ctx, RTAMD_E_LIMIT, "too many lights");
+    if (s->n_leaves < 0 || s->n_chain < 0 || s->n_tris < 0 || s->n_materials < 0 || s->n_csg_nodes < 0 || s->n_csg_roots < 0 ||
+        s->n_visits < 0)
+        return fail(ctx, RTAMD_E_INVALID, "negative count");
+    if ((s->n_lights && !s->lights) || (s->n_leaves && !s->leaves) || (s->n_chain && !s->chain) ||
+        (s->n_tris && (!s->tri_geom || !s->tri_normals)) || (s->n_materials && !s->materials) ||
+        (s->n_csg_nodes && !s->csg_nodes) || (s->n_csg_roots && !s->csg_roots) || (s->n_visits && !s->visits))
+        return fail(ctx, RTAMD_E_INVALID, "NULL array with a non-zero count");
+    std::vector<DLeaf> dl((size_t)s->n_leaves);
+    long long order = 0;
+    for (int i = 0; i < s->n_leaves; i++) {
+        const rtamd_leaf& L = s->leaves[i];
+        if (L.kind < RTAMD_SPHERE || L.kind > RTAMD_MESH) return fail(ctx, RTAMD_E_INVALID, "leaf kind out of range");
+        if (L.material < 0 || L.material >= s->n_materials) return fail(ctx, RTAMD_E_INVALID, "leaf material index out of range");
+        if (L.chain_len < 1 || L.chain_len > RTAMD_MAX_CHAIN || L.chain_start < 0 || L.chain_start + L.chain_len > s->n_chain)
+            return fail(ctx, RTAMD_E_INVALID, "leaf transform chain out of range");
+        if (L.eq_class < 0 || L.eq_class >= std::max(s->n_classes, 1)) return fail(ctx, RTAMD_E_INVALID, "leaf class out of range");
+        int slots = 0;
+        if (L.kind == RTAMD_MESH) {
+            if (L.tri_count < 1 || L.tri_start < 0 || (long long)L.tri_start + L.tri_count > s->n_tris)
+                return fail(ctx, RTAMD_E_INVALID, "mesh triangle range out of range");
+            slots = L.tri_count;
+        } else {
+            slots = 4;
+        }
+        DLeaf& D = dl[i];
+        std::memset(&D, 0, sizeof D);
+        std::memcpy(D.w2o, L.w2o, sizeof L.w2o);
+        D.p0 = L.p0, D.p1 = L.p1, D.kind = L.kind, D.flags = L.flags, D.material = L.material, D.eq_class = L.eq_class;
+        D.chain_start = L.chain_start, D.chain_len = L.chain_len, D.tri_start = L.tri_start, D.tri_count = L.tri_count;
+        D.order_base = (int)order;
+        order += slots;
+        if (order >= 0x7fffff00LL) return fail(ctx, RTAMD_E_LIMIT, "too many intersections slots for 32-bit order keys");
+    }
+    bool ri_safe = true;
+    for (int i = 0; i < s->n_materials; i++) {
+        const rtamd_material& M = s->materials[i];
+        if (M.pattern_kind < RTAMD_PAT_NONE || M.pattern_kind > RTAMD_PAT_TEST) return fail(ctx, RTAMD_E_INVALID, "pattern kind out of range");
+        if (!(std::isfinite(M.refractive_index) && M.refractive_index > 0.0)) ri_safe = false;
+    }
+    for (int i = 0; i < s->n_csg_roots; i++) {
+        const rtamd_csg_root& R = s->csg_roots[i];
+        if (R.node_start < 0 || R.node_count < 1 || R.node_start + R.node_count > s->n_csg_nodes || R.leaf_lo < 0 ||
+            R.leaf_hi > s->n_leaves || R.leaf_lo > R.leaf_hi)
+            return fail(ctx, RTAMD_E_INVALID, "csg root out of range");
+        if (R.leaf_hi - R.leaf_lo > RTAMD_MAX_CSG_LEAVES) return fail(ctx, RTAMD_E_LIMIT, "csg object with too many leaves");
+        for (int q = R.node_start; q < R.node_start + R.node_count; q++) {
+            const rtamd_csg_node& N = s->csg_nodes[q];
+            if (N.op < RTAMD_CSG_UNION || N.op > RTAMD_CSG_DIFFERENCE || N.leaf_lo < R.leaf_lo || N.leaf_hi > R.leaf_hi ||
+                N.leaf_lo > N.leaf_mid || N.leaf_mid > N.leaf_hi)
+                return fail(ctx, RTAMD_E_INVALID, "csg node out of range");
+        }
+    }
+    for (int i = 0; i < s->n_visits; i++) {
+        const rtamd_visit& V = s->visits[i];
+        int lim = (V.flags & RTAMD_VISIT_CSG) ? s->n_csg_roots : s->n_leaves;
+        if (V.unit < 0 || V.unit >= lim) return fail(ctx, RTAMD_E_INVALID, "visit unit out of range");
+        if (V.class_material < 0 || V.class_material >= s->n_materials) return fail(ctx, RTAMD_E_INVALID, "visit material out of range");
+    }
+    // ---- device copies
+    HIPCHK(ctx, hipDeviceSynchronize());
+    free_scene(ctx);
+    DScene d{};
+    d.cam = s->camera;
+    d.max_remaining = s->max_remaining, d.n_lights = s->n_lights, d.n_visits = s->n_visits, d.n_leaves = s->n_leaves;
+    d.ri_safe = ri_safe ? 1 : 0;
+    int rc;
+    if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &d.lights))) return rc;
+    if ((rc = upload(ctx, dl.data(), dl.size(), &d.leaves))) return rc;
+    if ((rc = upload(ctx, s->chain, (size_t)s->n_chain * 12, &d.chain))) return rc;
+    if ((rc = upload(ctx, s->tri_geom, (size_t)s->n_tris * 9, &d.tri_geom))) return rc;
+    if ((rc = upload(ctx, s->tri_normals, (size_t)s->n_tris * 9, &d.tri_normals))) return rc;
+    if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &d.materials))) return rc;
+    if ((rc = upload(ctx, s->csg_nodes, (size_t)s->n_csg_nodes, &d.csg_nodes))) return rc;
+    if ((rc = upload(ctx, s->csg_roots, (size_t)s->n_csg_roots, &d.csg_roots))) return rc;
+    if ((rc = upload(ctx, s->visits, (size_t)s->n_visits, &d.visits))) return rc;
+    if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
+    ctx->ds = d;
+    ctx->has_csg = s->n_csg_roots > 0;
+    ctx->have_scene = true;
+    return RTAMD_OK;
+}
+
+static int64_t part_rows(int vsize, const rtamd_rows* r) {
+    if (!r || r->tile_rows <= 0 || r->n_parts <= 0 || r->part < 0 || r->part >= r->n_parts) return -1;
+    int64_t rows = 0;
+    for (int64_t tile = r->part; tile * r->tile_rows < vsize; tile += r->n_parts)
+        rows += std::min<int64_t>(r->tile_rows, vsize - tile * r->tile_rows);
+    return rows;
+}
+
+int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows) {
+    if (!ctx || !ctx->have_scene) return -1;
+    return part_rows(ctx->ds.cam.vsize, rows);
+}
+
+static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
+    if (mode != RTAMD_MODE_STRICT && mode != RTAMD_MODE_FAST) return fail(ctx, RTAMD_E_INVALID, "unknown mode");
+    int rc = ensure_frames(ctx, std::max(1, w.remaining));
+    if (rc) return rc;
+    w.queue_head = ctx->d_queue;
+    w.stats = ctx->d_stats;
+    w.frames = ctx->d_frames;
+    w.total_lanes = ctx->total_lanes;
+    int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->has_csg ? 1 : 0], (w.n_pixels + 255) / 256);
+    blocks = std::max(blocks, 1);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, ctx->has_csg, blocks, stream)
+                                             : rtamd_launch_fast(ctx->ds, w, ctx->has_csg, blocks, stream);
+    if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    return RTAMD_OK;
+}
+
+int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream) {
+    if (!ctx) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NO_SCENE, "no scene uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int64_t nrows = part_rows(ctx->ds.cam.vsize, rows);
+    if (nrows < 0) return fail(ctx, RTAMD_E_INVALID, "bad rows specification");
+    if (nrows == 0) return RTAMD_OK;
+    DWork w{};
+    w.hsize = ctx->ds.cam.hsize, w.vsize = ctx->ds.cam.vsize;
+    w.tile_rows = rows->tile_rows, w.part = rows->part, w.n_parts = rows->n_parts;
+    w.remaining = ctx->ds.max_remaining;
+    w.n_pixels = nrows * ctx->ds.cam.hsize;
+    w.custom_rays = nullptr;
+    w.out_rgb = d_rgb, w.out_rgb8 = d_rgb8;
+    return launch(ctx, mode, w, (hipStream_t)stream);
+}
+
+int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
+    if (!ctx) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NO_SCENE, "no scene uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t npx = (size_t)ctx->ds.cam.hsize * ctx->ds.cam.vsize;
+    double* d_rgb = nullptr;
+    uint8_t* d_u8 = nullptr;
+    if (h_rgb) HIPCHK(ctx, hipMalloc(&d_rgb, npx * 3 * sizeof(double)));
+    if (h_rgb8) HIPCHK(ctx, hipMalloc(&d_u8, npx * 3));
+    rtamd_rows all{ctx->ds.cam.vsize, 0, 1};
+    int rc = rtamd_render_rows(ctx, &all, mode, d_rgb, d_u8, nullptr);
+    if (rc == RTAMD_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess && h_rgb) e = hipMemcpy(h_rgb, d_rgb, npx * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && h_rgb8) e = hipMemcpy(h_rgb8, d_u8, npx * 3, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, RTAMD_E_HIP, std::string("render: ") + hipGetErrorString(e));
+    }
+    if (d_rgb) (void)hipFree(d_rgb);
+    if (d_u8) (void)hipFree(d_u8);
+    if (rc == RTAMD_OK) {
+        unsigned long long ovf = 0;
+        if (hipMemcpy(&ovf, ctx->d_stats + ST_CSG_OVERFLOW, sizeof ovf, hipMemcpyDeviceToHost) == hipSuccess && ovf)
+            rc = fail(ctx, RTAMD_E_OVERFLOW, "a per-lane CSG intersection list overflowed (RTAMD_CSG_LIST_CAP)");
+    }
+    return rc;
+}
+
+int rtamd_color_at(rtamd_ctx* ctx, int mode, const double* h_rays, int64_t n, int remaining, double* h_rgb) {
+    if (!ctx || !h_rays || !h_rgb || n < 0) return RTAMD_E_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RTAMD_E_NO_SCENE, "no scene uploaded");
+    if (remaining < 0 || remaining > RTAMD_MAX_REMAINING) return fail(ctx, RTAMD_E_LIMIT, "remaining out of range");
+    if (n == 0) return RTAMD_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *d_rays = nullptr, *d_rgb = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_rays, (size_t)n * 6 * sizeof(double)));
+    HIPCHK(ctx, hipMalloc(&d_rgb, (size_t)n * 3 * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(d_rays, h_rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    DWork w{};
+    w.hsize = ctx->ds.cam.hsize, w.vsize = ctx->ds.cam.vsize;
+    w.tile_rows = 1, w.part = 0, w.n_parts = 1;
+    w.remaining = remaining;
+    w.n_pixels = n;
+    w.custom_rays = d_rays;
+    w.out_rgb = d_rgb, w.out_rgb8 = nullptr;
+    int rc = launch(ctx, mode, w, nullptr);
+    if (rc == RTAMD_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(h_rgb, d_rgb, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, RTAMD_E_HIP, std::string("color_at: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_rays);
+    (void)hipFree(d_rgb);
+    return rc;
+}
+
+int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
+    if (!ctx || !out) return RTAMD_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof *out);
+    if (ctx->timed) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        out->kernel_ms = ms;
+    }
+    unsigned long long h[ST_COUNT];
+    HIPCHK(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    out->primary_rays = h[ST_PRIMARY], out->shadow_rays = h[ST_SHADOW_RAYS], out->reflect_rays = h[ST_REFLECT];
+    out->refract_rays = h[ST_REFRACT], out->container_passes = h[ST_CONTAINER];
+    out->rays = h[ST_PRIMARY] + h[ST_SHADOW_RAYS] + h[ST_REFLECT] + h[ST_REFRACT] + h[ST_CONTAINER];
+    out->shade_points = h[ST_SHADE_POINTS], out->light_samples = h[ST_LIGHT_SAMPLES], out->csg_overflows = h[ST_CSG_OVERFLOW];
+    return RTAMD_OK;
+}
+
+int rtamd_reset_stats(rtamd_ctx* ctx) {
+    if (!ctx) return RTAMD_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemset(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long)));
+    return RTAMD_OK;
+}
+
