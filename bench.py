@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + secondary) and frame time of the GPU render loop.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one frame of the workload (default: scenes/cover.yaml of the reference at 3840x2160, recursion
+budget 4), rendered with the scene already resident in HBM: every rank renders its cyclic row tiles
+(tile i -> rank i % N), the float64 frame (the reference's Canvas) is gathered on rank 0 over RCCL and
+put back in row order.  Rank 0 prints ONE JSON line.  `value` = rays traced by all ranks per second
+(primary, reflection, refraction and shadow rays; the n1/n2 container passes are not counted).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X: 256 CU x 64 FP64 FMA lanes/clk x 2 flop x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+# algorithmic flops of one leaf test, ray transform included (33 flops; a plane needs only the y row)
+LEAF_FLOPS = {"sphere": 33 + 29, "plane": 14, "cube": 33 + 23, "cylinder_open": 33 + 34, "cylinder_closed": 33 + 55,
+              "cone_open": 33 + 40, "cone_closed": 33 + 63, "tri": 51}
+SHADE_POINT_FLOPS = 100
+LIGHT_SAMPLE_FLOPS = 60
+
+
+def flops_per_ray(sg_path):
+    """Sum over the leaves of the scene graph; a run of triangles pays the ray transform once."""
+    total, in_run = 0, False
+    with open(sg_path) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0] != "node":
+                continue
+            kind = t[1]
+            if kind in ("tri", "stri"):
+                total += LEAF_FLOPS["tri"] + (0 if in_run else 33)
+                in_run = True
+                continue
+            in_run = False
+            if kind in ("sphere", "plane", "cube"):
+                total += LEAF_FLOPS[kind]
+            elif kind in ("cylinder", "cone"):
+                total += LEAF_FLOPS[f"{kind}_{'closed' if t[10] == '1' else 'open'}"]
+    return total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="cover")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rt = importlib.import_module("ray-tracer_amd")
+    mode = rt.MODE_FAST if a.mode == "fast" else rt.MODE_STRICT
+    sg = os.path.join(ROOT, "tests", "golden", "scenes", a.scene + ".sg")
+    scene = rt.Scene.from_sg(sg).set_resolution(a.width, a.height)
+    ctx = rt.Context(local_rank)
+    ctx.upload(scene.flatten())
+    W, H, R = a.width, a.height, a.tile_rows
+
+    my_rows = ctx.part_rows(R, rank, world)
+    max_rows = max(ctx.part_rows(R, p, world) for p in range(world))
+    local = torch.empty((max_rows, W, 3), dtype=torch.float64, device=dev)
+    frame = torch.empty((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+    gathered = [torch.empty_like(local) for _ in range(world)] if (rank == 0 and world > 1) else None
+    if rank == 0 and world > 1:  # where the rows of each part go in the frame
+        dst_rows = []
+        for p in range(world):
+            rows = [y for t in range(p, (H + R - 1) // R, world) for y in range(t * R, min(H, (t + 1) * R))]
+            dst_rows.append(torch.tensor(rows, dtype=torch.int64, device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        if world == 1:
+            ctx.render_rows(R, 0, 1, mode, d_rgb=frame.data_ptr(), stream=stream)
+            return
+        ctx.render_rows(R, rank, world, mode, d_rgb=local.data_ptr(), stream=stream)
+        dist.gather(local, gathered, dst=0)
+        if rank == 0:
+            for p in range(world):
+                frame.index_copy_(0, dst_rows[p], gathered[p][: dst_rows[p].numel()])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    ctx.reset_stats()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        if world == 1:  # bracket the render kernel itself on its stream
+            ev[k][0].record()
+            step()
+            ev[k][1].record()
+        else:
+            ev[k][0].record()
+            ctx.render_rows(R, rank, world, mode, d_rgb=local.data_ptr(), stream=stream)
+            ev[k][1].record()
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                for p in range(world):
+                    frame.index_copy_(0, dst_rows[p], gathered[p][: dst_rows[p].numel()])
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    counts = torch.tensor([st.primary_rays + st.shadow_rays + st.reflect_rays + st.refract_rays, st.shade_points,
+                           st.light_samples, st.container_passes], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+    rays, shade_points, light_samples, containers = [float(x) / a.steps for x in counts]
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        fpr = flops_per_ray(sg)
+        flops = (rays + containers) * fpr + shade_points * SHADE_POINT_FLOPS + light_samples * LIGHT_SAMPLE_FLOPS
+        achieved = flops / (kernel_ms * 1e-3) / 1e12  # per rank-kernel: flops of all ranks / slowest kernel
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_hbm_{a.scene}_{W}x{H}_{a.mode}.json")
+        if world == 1 and os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Mrays/sec (primary+secondary) & frame time, cover.yaml 4K, 1/2/4/8 MI355X",
+            "value": rays / (ms_per_step * 1e-3) / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.scene} scene graph at {W}x{H}, recursion budget 4, {a.mode} arithmetic",
+                       "rays_per_frame": rays, "pixels": W * H, "row_tiles": f"cyclic, {R} rows", "parallelism": f"rows{world}"},
+            "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": achieved / (FP64_VALU_PEAK_TFLOPS * world), "traffic": traffic,
+                         "kernel_ms": kernel_ms, "flops_per_ray": fpr, "algorithmic_flops_per_frame": flops,
+                         "hbm_algorithmic_bytes_per_frame": W * H * 24,
+                         "hbm_frac": W * H * 24 / (kernel_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
+        }
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(a, sg, frame, rt)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, sg, frame, rt):
+    """The oracle in `faithful` mode (per-call inverses, per-light duplicated recursion: the work the
+    reference does), one thread, on a regular subsample of the frame's pixels sized to the time budget."""
+    import oracle_lib
+    W, H = a.width, a.height
+    o = oracle_lib.OracleScene(sg)
+    npx = W * H
+    probe = np.linspace(0, npx - 1, 96).astype(np.int64)
+    t0 = time.perf_counter()
+    o.render_pixels(probe, W, H, faithful=True)
+    per_px = (time.perf_counter() - t0) / probe.size
+    n = int(max(256, min(npx, a.cpu_seconds / max(per_px, 1e-9))))
+    stride = max(1, npx // n)
+    pix = np.arange(stride // 2, npx, stride, dtype=np.int64)
+    t0 = time.perf_counter()
+    rgb, u8, st = o.render_pixels(pix, W, H, faithful=True)
+    dt = time.perf_counter() - t0
+    import torch
+    gpu = frame.reshape(-1, 3)[torch.from_numpy(pix).to(frame.device)].cpu().numpy()
+    g8 = rt.quantize(gpu)
+    d8 = np.abs(g8.astype(int) - u8.astype(int)).max(axis=1)
+    base = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{pix.size} pixels (every {stride}-th of the {W}x{H} frame), oracle in faithful mode, 1 thread, {dt:.1f} s",
+            "rays_reference_equivalent_per_frame": st["rays"] / pix.size * npx,
+            "est_frame_seconds": dt / pix.size * npx, "host_cpus": os.cpu_count()}
+    parity = {"pixels_checked": int(pix.size), "max_abs_f64": float(np.abs(gpu - rgb).max()),
+              "u8_within_1_lsb": float((d8 <= 1).mean()), "u8_equal": float((d8 == 0).mean())}
+    return base, parity
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,7 @@ enum { RTAMD_CSG_UNION = 0, RTAMD_CSG_INTERSECTION = 1, RTAMD_CSG_DIFFERENCE = 2
 #define RTAMD_MAX_CHAIN 8           /* transform levels (ancestors + own) of one leaf */
 #define RTAMD_MAX_CSG_LEAVES 64     /* leaves below one top-most CSG node */
 #define RTAMD_CSG_LIST_CAP 24       /* per-lane intersection list of one top-most CSG node */
+#define RTAMD_MAX_MESH_TRIS 4096    /* triangles in one MESH leaf; the flattening host splits longer runs */
 #define RTAMD_MAX_REMAINING 8       /* recursion budget supported (the reference renders with 4) */
 
 /* One primitive leaf, in depth-first order of the object tree (= the order in which the

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+LIB_DIR = os.environ.get("RTAMD_LIB_DIR") or os.path.join(_HERE, "lib")  # override: development only
 
 MODE_STRICT = 0
 MODE_FAST = 1

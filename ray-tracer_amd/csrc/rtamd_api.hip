@@ -14,9 +14,10 @@
 #include "rtamd_device.h"
 
 static_assert(sizeof(rtamd_leaf) == 144, "rtamd_leaf layout");
-static_assert(sizeof(DLeaf) == 160, "DLeaf layout");
+static_assert(sizeof(DLeaf) == 176, "DLeaf layout");
 static_assert(sizeof(rtamd_material) == 232, "rtamd_material layout");
 static_assert(sizeof(rtamd_visit) == 16, "rtamd_visit layout");
+static_assert(sizeof(DVisit) == 128, "DVisit layout");
 
 struct rtamd_ctx {
     int device = 0;
@@ -31,6 +32,7 @@ struct rtamd_ctx {
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
     int max_blocks[2][2] = {{0, 0}, {0, 0}};  // [mode][has_csg]
+    int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
 };
@@ -93,9 +95,10 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     for (int m = 0; m < 2; m++)
         for (int c = 0; c < 2; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
+    ctx->stat_blocks = mb;
     if ((e = hipMalloc(&ctx->d_queue, 256)) != hipSuccess) return bail("hipMalloc(queue)", e);
-    if ((e = hipMalloc(&ctx->d_stats, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stats)", e);
-    if ((e = hipMemset(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMalloc(&ctx->d_stats, (size_t)mb * RTAMD_STAT_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stats)", e);
+    if ((e = hipMemset(ctx->d_stats, 0, (size_t)mb * RTAMD_STAT_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     *out = ctx;
@@ -153,6 +156,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if (s->camera.hsize <= 0 || s->camera.vsize <= 0) return fail(ctx, RTAMD_E_INVALID, "camera size must be positive");
     if (s->max_remaining < 0 || s->max_remaining > RTAMD_MAX_REMAINING) return fail(ctx, RTAMD_E_LIMIT, "max_remaining out of range");
     if (s->n_lights < 0 || s->n_lights > RTAMD_MAX_LIGHTS) return fail(ctx, RTAMD_E_LIMIT, "too many lights");
+    if (s->n_leaves >= (1 << (31 - RTAMD_KEY_SHIFT))) return fail(ctx, RTAMD_E_LIMIT, "too many leaves");
     if (s->n_leaves < 0 || s->n_chain < 0 || s->n_tris < 0 || s->n_materials < 0 || s->n_csg_nodes < 0 || s->n_csg_roots < 0 ||
         s->n_visits < 0)
         return fail(ctx, RTAMD_E_INVALID, "negative count");
@@ -171,6 +175,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if (L.eq_class < 0 || L.eq_class >= std::max(s->n_classes, 1)) return fail(ctx, RTAMD_E_INVALID, "leaf class out of range");
         int slots = 0;
         if (L.kind == RTAMD_MESH) {
+            if (L.tri_count > RTAMD_MAX_MESH_TRIS) return fail(ctx, RTAMD_E_LIMIT, "mesh leaf with more than RTAMD_MAX_MESH_TRIS triangles");
             if (L.tri_count < 1 || L.tri_start < 0 || (long long)L.tri_start + L.tri_count > s->n_tris)
                 return fail(ctx, RTAMD_E_INVALID, "mesh triangle range out of range");
             slots = L.tri_count;
@@ -183,6 +188,12 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         D.p0 = L.p0, D.p1 = L.p1, D.kind = L.kind, D.flags = L.flags, D.material = L.material, D.eq_class = L.eq_class;
         D.chain_start = L.chain_start, D.chain_len = L.chain_len, D.tri_start = L.tri_start, D.tri_count = L.tri_count;
         D.order_base = (int)order;
+        const double* m = L.w2o;
+        if (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0 && m[0] != 0.0 && m[5] != 0.0 &&
+            m[10] != 0.0) {
+            D.flags |= DLEAF_DIAG;
+            D.inv_diag[0] = 1.0 / m[0], D.inv_diag[1] = 1.0 / m[5], D.inv_diag[2] = 1.0 / m[10];
+        }
         order += slots;
         if (order >= 0x7fffff00LL) return fail(ctx, RTAMD_E_LIMIT, "too many intersections slots for 32-bit order keys");
     }
@@ -227,7 +238,32 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &d.materials))) return rc;
     if ((rc = upload(ctx, s->csg_nodes, (size_t)s->n_csg_nodes, &d.csg_nodes))) return rc;
     if ((rc = upload(ctx, s->csg_roots, (size_t)s->n_csg_roots, &d.csg_roots))) return rc;
-    if ((rc = upload(ctx, s->visits, (size_t)s->n_visits, &d.visits))) return rc;
+    std::vector<DVisit> dv((size_t)s->n_visits);
+    std::vector<int32_t> class_mat((size_t)std::max(s->n_classes, 1), 0);
+    for (int i = 0; i < s->n_visits; i++) {
+        const rtamd_visit& V = s->visits[i];
+        DVisit& D = dv[i];
+        std::memset(&D, 0, sizeof D);
+        if (V.eq_class < 0 || V.eq_class >= std::max(s->n_classes, 1) || V.eq_class >= (1 << 23))
+            return fail(ctx, RTAMD_E_INVALID, "visit class out of range");
+        class_mat[V.eq_class] = V.class_material;
+        D.unit = V.unit;
+        D.vflags_class = (V.flags & 0xffu) | ((uint32_t)V.eq_class << 8);
+        if (!(V.flags & RTAMD_VISIT_CSG)) {
+            const DLeaf& L = dl[V.unit];
+            std::memcpy(D.w2o, L.w2o, sizeof D.w2o);
+            if (L.flags & DLEAF_DIAG) D.w2o[1] = L.inv_diag[0], D.w2o[2] = L.inv_diag[1], D.w2o[4] = L.inv_diag[2];
+            D.p0 = L.p0, D.p1 = L.p1;
+            if (L.kind == RTAMD_MESH) {
+                int32_t tr[2] = {L.tri_start, L.tri_count};
+                std::memcpy(&D.p0, tr, sizeof tr);
+            }
+            D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
+            D.order_base = L.order_base;
+        }
+    }
+    if ((rc = upload(ctx, class_mat.data(), class_mat.size(), &d.class_material))) return rc;
+    if ((rc = upload(ctx, dv.data(), dv.size(), &d.visits))) return rc;
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
     ctx->ds = d;
     ctx->has_csg = s->n_csg_roots > 0;
@@ -305,8 +341,8 @@ int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
     if (d_rgb) (void)hipFree(d_rgb);
     if (d_u8) (void)hipFree(d_u8);
     if (rc == RTAMD_OK) {
-        unsigned long long ovf = 0;
-        if (hipMemcpy(&ovf, ctx->d_stats + ST_CSG_OVERFLOW, sizeof ovf, hipMemcpyDeviceToHost) == hipSuccess && ovf)
+        rtamd_stats st;
+        if (ctx->has_csg && rtamd_get_stats(ctx, &st) == RTAMD_OK && st.csg_overflows)
             rc = fail(ctx, RTAMD_E_OVERFLOW, "a per-lane CSG intersection list overflowed (RTAMD_CSG_LIST_CAP)");
     }
     return rc;
@@ -350,12 +386,21 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         out->kernel_ms = ms;
     }
-    unsigned long long h[ST_COUNT];
-    HIPCHK(ctx, hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> slots((size_t)ctx->stat_blocks * RTAMD_STAT_STRIDE);
+    HIPCHK(ctx, hipMemcpy(slots.data(), ctx->d_stats, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long h[ST_COUNT] = {};
+    for (int b = 0; b < ctx->stat_blocks; b++)
+        for (int k = 0; k < ST_COUNT; k++) h[k] += slots[(size_t)b * RTAMD_STAT_STRIDE + k];
     out->primary_rays = h[ST_PRIMARY], out->shadow_rays = h[ST_SHADOW_RAYS], out->reflect_rays = h[ST_REFLECT];
     out->refract_rays = h[ST_REFRACT], out->container_passes = h[ST_CONTAINER];
     out->rays = h[ST_PRIMARY] + h[ST_SHADOW_RAYS] + h[ST_REFLECT] + h[ST_REFRACT] + h[ST_CONTAINER];
     out->shade_points = h[ST_SHADE_POINTS], out->light_samples = h[ST_LIGHT_SAMPLES], out->csg_overflows = h[ST_CSG_OVERFLOW];
+    if (getenv("RTAMD_PROFILE_DUMP")) {  // diagnostic builds (-DRTAMD_PROFILE) only
+        const unsigned long long* p = slots.data() + ST_COUNT;
+        if (p[3])
+            fprintf(stderr, "[rtamd profile] wave-iterations %llu: refill %.0f, traversal %.0f, post %.0f cycles per iteration\n", p[3],
+                    (double)p[0] / p[3], (double)p[1] / p[3], (double)p[2] / p[3]);
+    }
     return RTAMD_OK;
 }
 
@@ -363,7 +408,7 @@ int rtamd_reset_stats(rtamd_ctx* ctx) {
     if (!ctx) return RTAMD_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());
-    HIPCHK(ctx, hipMemset(ctx->d_stats, 0, ST_COUNT * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMemset(ctx->d_stats, 0, (size_t)ctx->stat_blocks * RTAMD_STAT_STRIDE * sizeof(unsigned long long)));
     return RTAMD_OK;
 }
 

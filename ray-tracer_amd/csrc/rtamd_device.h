@@ -5,7 +5,7 @@
 
 #include "../../include/rtamd.h"
 
-// Device copy of an rtamd_leaf plus what the upload derives from the scene. 160 bytes.
+// Device copy of an rtamd_leaf plus what the upload derives from the scene. 176 bytes.
 struct DLeaf {
     double w2o[12];
     double p0, p1;
@@ -18,7 +18,20 @@ struct DLeaf {
     int32_t tri_start;
     int32_t tri_count;
     int32_t order_base;  // rank of this leaf's first possible intersection in depth-first order
-    int32_t pad_[3];
+    int32_t pad_;
+    double inv_diag[3];  // DLEAF_DIAG: 1 / w2o[0], 1 / w2o[5], 1 / w2o[10]
+};
+#define DLEAF_DIAG 0x100u  // device-side flag: the 3x3 part of w2o is diagonal
+
+// One step of the traversal order, self-contained for a plain leaf so that one batch of scalar
+// loads brings everything its intersection needs. 128 bytes, 16-byte aligned.
+struct alignas(16) DVisit {
+    double w2o[12];         //   0  DLEAF_DIAG leaves: slots 1, 2, 4 (zeros of the matrix) hold 1/w2o[0], 1/w2o[5], 1/w2o[10]
+    double p0, p1;          //  96  cylinder/cone min, max; MESH: the bytes of p0 hold int32 tri_start, tri_count
+    uint32_t kind_flags;    // 112  kind | leaf flags << 8
+    int32_t order_base;     // 116
+    int32_t unit;           // 120  leaf index, or csg root index when the visit has RTAMD_VISIT_CSG
+    uint32_t vflags_class;  // 124  RTAMD_VISIT_* | eq_class << 8
 };
 
 struct DScene {
@@ -37,7 +50,8 @@ struct DScene {
     const rtamd_material* materials;
     const rtamd_csg_node* csg_nodes;
     const rtamd_csg_root* csg_roots;
-    const rtamd_visit* visits;
+    const DVisit* visits;
+    const int32_t* class_material;  // material of each equality class
 };
 
 // Per-launch counters, one 64-bit word each (device memory, accumulated with atomics).
@@ -53,6 +67,8 @@ enum {
     ST_COUNT
 };
 
+#define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
+#define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
 #define RTAMD_FRAME_F64 20   // doubles per saved shade-point frame
 #define RTAMD_CHUNK 256      // pixels a wave takes from the queue at a time
 
@@ -67,7 +83,7 @@ struct DWork {
     uint8_t* out_rgb8;          // may be NULL
     // scratch the library owns
     unsigned long long* queue_head;  // next unassigned pixel
-    unsigned long long* stats;       // ST_COUNT words
+    unsigned long long* stats;       // [blocks][RTAMD_STAT_STRIDE]: every block adds into its own slot
     double* frames;                  // [max_remaining][RTAMD_FRAME_F64][total_lanes]
     int64_t total_lanes;
 };

@@ -315,7 +315,7 @@ struct Flattener {
                 const Shape* first = leaf_shape.back();
                 bool smooth = (L.flags & RTAMD_LEAF_SMOOTH) != 0;
                 bool shadow = (L.flags & RTAMD_LEAF_SHADOW) != 0;
-                if (L.kind == RTAMD_MESH && L.material == mat && smooth == t.is_smooth && shadow == s.shadow() &&
+                if (L.kind == RTAMD_MESH && L.tri_count < RTAMD_MAX_MESH_TRIS && L.material == mat && smooth == t.is_smooth && shadow == s.shadow() &&
                     bits_eq(first->transform(), s.transform()) && leaf_root.back() == root &&
                     first->parent_transforms().size() == s.parent_transforms().size() &&
                     (s.parent_transforms().empty() ||
