@@ -85,6 +85,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     rt = importlib.import_module("ray-tracer_amd")
+    rows_mod = importlib.import_module("ray-tracer_amd.rows")
     mode = rt.MODE_FAST if a.mode == "fast" else rt.MODE_STRICT
     sg = os.path.join(ROOT, "tests", "golden", "scenes", a.scene + ".sg")
     scene = rt.Scene.from_sg(sg).set_resolution(a.width, a.height)
@@ -92,27 +93,15 @@ def main():
     ctx.upload(scene.flatten())
     W, H, R = a.width, a.height, a.tile_rows
 
-    my_rows = ctx.part_rows(R, rank, world)
-    max_rows = max(ctx.part_rows(R, p, world) for p in range(world))
-    local = torch.empty((max_rows, W, 3), dtype=torch.float64, device=dev)
-    frame = torch.empty((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
-    gathered = [torch.empty_like(local) for _ in range(world)] if (rank == 0 and world > 1) else None
-    if rank == 0 and world > 1:  # where the rows of each part go in the frame
-        dst_rows = []
-        for p in range(world):
-            rows = [y for t in range(p, (H + R - 1) // R, world) for y in range(t * R, min(H, (t + 1) * R))]
-            dst_rows.append(torch.tensor(rows, dtype=torch.int64, device=dev))
+    if ctx.part_rows(R, rank, world) != len(rows_mod.part_row_indices(H, R, rank, world)):
+        raise SystemExit("row partition of the library and of rows.py disagree")
+    fg = rows_mod.FrameGather(W, H, R, rank, world, dev)
+    frame = fg.frame
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        if world == 1:
-            ctx.render_rows(R, 0, 1, mode, d_rgb=frame.data_ptr(), stream=stream)
-            return
-        ctx.render_rows(R, rank, world, mode, d_rgb=local.data_ptr(), stream=stream)
-        dist.gather(local, gathered, dst=0)
-        if rank == 0:
-            for p in range(world):
-                frame.index_copy_(0, dst_rows[p], gathered[p][: dst_rows[p].numel()])
+        ctx.render_rows(R, rank, world, mode, d_rgb=fg.local.data_ptr(), stream=stream)
+        fg.gather()
 
     def sync():
         if world > 1:
@@ -127,18 +116,10 @@ def main():
     sync()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        if world == 1:  # bracket the render kernel itself on its stream
-            ev[k][0].record()
-            step()
-            ev[k][1].record()
-        else:
-            ev[k][0].record()
-            ctx.render_rows(R, rank, world, mode, d_rgb=local.data_ptr(), stream=stream)
-            ev[k][1].record()
-            dist.gather(local, gathered, dst=0)
-            if rank == 0:
-                for p in range(world):
-                    frame.index_copy_(0, dst_rows[p], gathered[p][: dst_rows[p].numel()])
+        ev[k][0].record()  # events bracket the render kernel itself, on the stream it is launched on
+        ctx.render_rows(R, rank, world, mode, d_rgb=fg.local.data_ptr(), stream=stream)
+        ev[k][1].record()
+        fg.gather()
     sync()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()

@@ -63,8 +63,9 @@ typedef struct rtamd_leaf {
     int32_t kind;        /* RTAMD_SPHERE ... RTAMD_MESH */
     uint32_t flags;      /* RTAMD_LEAF_* */
     int32_t material;    /* index into materials (after Group::refresh_parents inheritance) */
-    int32_t eq_class;    /* id of the first leaf (DFS order) that is value-equal to this one under
-                            `PartialEq for dyn Shape` (src/shape.rs:23-27,119-123) */
+    int32_t eq_class;    /* 0 .. n_classes-1: which set of leaves that are value-equal under `PartialEq for
+                            dyn Shape` (src/shape.rs:23-27,119-123) this one belongs to; classes are numbered
+                            by first appearance in DFS order */
     int32_t chain_start; /* first of chain_len 3x4 matrices in `chain`: inverse of each entry of the
                             leaf's parent_transforms (root first), then inverse of its own transform
                             (src/shape.rs:49-70). Leaves below a CSG node have only their own. */
@@ -177,7 +178,8 @@ void rtamd_ctx_destroy(rtamd_ctx* ctx);
 const char* rtamd_last_error(const rtamd_ctx* ctx); /* ctx may be NULL: creation errors */
 
 /* Replaces the scene state Camera::render reads (World after refresh_parents, Camera):
- * src/scene.rs:236-238. Validates indices and limits; copies to the device. */
+ * src/scene.rs:236-238. Validates indices and limits, then copies to the device. A scene that fails
+ * validation leaves the previously uploaded one (if any) in place. */
 int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* scene);
 
 /* Number of rows / pixels a rows-spec selects for the uploaded scene. */

@@ -1016,4 +1016,30 @@ int orc_render_pixels(void* s, int mode, int hsize, int vsize, const int64_t* pi
     return 0;
 }
 
+// World::color_at(ray, remaining) (src/scene.rs:53-63) for n caller-supplied rays: rays = n x 6
+// doubles (origin xyz, direction xyz), out_rgb = n x 3.  mode as above.  Returns 0 or -1.
+int orc_color_at(void* s, int mode, const double* rays, int64_t n, int remaining, double* out_rgb) {
+    auto* sc = (orc::Scene*)s;
+    orc::world_refresh_parents(sc->world);
+    orc::Ctx c;
+    c.faithful = mode == 1;
+    void* cache = orc::new_thread_cache();
+    orc::set_thread_cache(cache);
+    int rc = 0;
+    try {
+        for (int64_t k = 0; k < n; k++) {
+            const double* q = rays + 6 * k;
+            orc::Ray r{orc::pt(q[0], q[1], q[2]), orc::vec(q[3], q[4], q[5])};
+            orc::Color col = orc::color_at(c, sc->world, r, remaining);
+            out_rgb[3 * k + 0] = col.r, out_rgb[3 * k + 1] = col.g, out_rgb[3 * k + 2] = col.b;
+        }
+    } catch (std::exception& e) {
+        g_err = e.what();
+        rc = -1;
+    }
+    orc::set_thread_cache(nullptr);
+    orc::free_thread_cache(cache);
+    return rc;
+}
+
 }  // extern "C"

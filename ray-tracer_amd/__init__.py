@@ -15,6 +15,17 @@ import os
 
 import numpy as np
 
+# A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64; when it is installed
+# it has to be loaded before librtamd.so pulls in the system one, or device-code registration of the
+# second arrival fails ("unknown error" at the first kernel query).  Callers use torch anyway for device
+# buffers, streams and torch.distributed.
+try:
+    import torch  # noqa: F401
+except ImportError:  # a host without PyTorch: the ROCm runtime of the system is the only one
+    pass
+
+from . import abi
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.environ.get("RTAMD_LIB_DIR") or os.path.join(_HERE, "lib")  # override: development only
 
@@ -117,6 +128,11 @@ class Flat:
     def view(self):
         return _host.rth_flat_view(self._h)
 
+    @property
+    def scene(self):
+        """The ``rtamd_scene`` as a ctypes structure (pointers stay valid while this object lives)."""
+        return abi.SceneStruct.from_address(self.view)
+
     def __del__(self):
         if getattr(self, "_h", None):
             _host.rth_free_flat(self._h)
@@ -194,6 +210,7 @@ class Context:
             raise RtamdError(f"rtamd_ctx_create({device}) = {rc}: {_gpu.rtamd_last_error(None).decode()}")
         self._h = p
         self._flat = None
+        self._size = None
 
     def _chk(self, rc):
         if rc:
@@ -202,7 +219,19 @@ class Context:
     def upload(self, flat):
         self._chk(_gpu.rtamd_scene_upload(self._h, flat.view))
         self._flat = flat
+        self._size = (flat.scene.camera.hsize, flat.scene.camera.vsize)
         return self
+
+    def upload_struct(self, scene_struct):
+        """Upload an ``abi.SceneStruct`` built or edited in Python; returns the status code (no exception)."""
+        rc = _gpu.rtamd_scene_upload(self._h, C.byref(scene_struct))
+        if rc == 0:
+            self._flat = None
+            self._size = (scene_struct.camera.hsize, scene_struct.camera.vsize)
+        return rc
+
+    def last_error(self):
+        return _gpu.rtamd_last_error(self._h).decode()
 
     def part_rows(self, tile_rows, part, n_parts):
         r = Rows(tile_rows, part, n_parts)
@@ -215,6 +244,9 @@ class Context:
                                          C.c_void_p(stream or None)))
 
     def render(self, hsize, vsize, mode=MODE_FAST, want_u8=False):
+        """Whole frame into host arrays; (hsize, vsize) must be the resolution of the uploaded scene."""
+        if getattr(self, "_size", None) is not None and self._size != (hsize, vsize):
+            raise RtamdError(f"the uploaded scene is {self._size[0]}x{self._size[1]}, not {hsize}x{vsize}")
         rgb = np.empty((vsize, hsize, 3), dtype=np.float64)
         u8 = np.empty((vsize, hsize, 3), dtype=np.uint8) if want_u8 else None
         self._chk(_gpu.rtamd_render(self._h, mode, rgb.ctypes.data, u8.ctypes.data if want_u8 else None))

@@ -1,0 +1,42 @@
+"""One rank of the CPU rehearsal of the multi-GPU frame assembly (started by test_distributed.py).
+
+The rows a rank would render on its GPU are produced here by the CPU oracle -- the exchange, the row
+partition and the reassembly are the code bench.py runs (ray-tracer_amd/rows.py), over gloo."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    w, h, tile_rows, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows_mod = importlib.import_module("ray-tracer_amd.rows")
+    import oracle_lib
+    o = oracle_lib.OracleScene(os.path.join(ROOT, "tests", "golden", "scenes", "cover.sg"))
+    fg = rows_mod.FrameGather(w, h, tile_rows, rank, world, torch.device("cpu"))
+    mine = rows_mod.part_row_indices(h, tile_rows, rank, world)
+    assert fg.n_rows == len(mine)
+    fg.local.fill_(float("nan"))
+    if len(mine):
+        pix = (mine[:, None] * w + np.arange(w)[None, :]).ravel()
+        rgb, _, _ = o.render_pixels(pix, w, h)
+        fg.local[: len(mine)] = torch.from_numpy(rgb.reshape(len(mine), w, 3))
+    for _ in range(2):  # the exchange is repeatable (bench.py calls it every step)
+        frame = fg.gather()
+    dist.barrier()
+    if rank == 0:
+        np.save(out, frame.numpy())
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,8 @@ def lib():
         _lib.orc_render_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_int, C.POINTER(OrcStats)]
         _lib.orc_render_pixels.restype = C.c_int
+        _lib.orc_color_at.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        _lib.orc_color_at.restype = C.c_int
     return _lib
 
 
@@ -59,6 +61,14 @@ class OracleScene:
         if rc:
             raise RuntimeError("oracle: " + lib().orc_last_error().decode())
         return rgb, u8, {n: getattr(st, n) for n, _ in st._fields_}
+
+    def color_at(self, rays, remaining, faithful=False):
+        """rays: (n,6) origin+direction -> (n,3) colours of World::color_at(ray, remaining)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.empty((rays.shape[0], 3), dtype=np.float64)
+        if lib().orc_color_at(self._h, 1 if faithful else 0, rays.ctypes.data, rays.shape[0], remaining, out.ctypes.data):
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        return out
 
     def render(self, hsize=0, vsize=0, faithful=False, threads=1):
         if hsize <= 0:

@@ -1,0 +1,90 @@
+"""BASELINE-size frames (3840x2160 and 7680x4320) on the GPU.  The oracle cannot render these in the time
+of a test, so parity is checked on a lattice of pixels it can, and on properties that do not depend on
+the size: the 8-bit output is the quantisation of the f64 output, a frame rendered in row parts equals
+the frame rendered whole, two renders are identical, and strict and fast arithmetic agree to 1e-8 except
+on the few pixels whose ray grazes a discontinuity (a checker boundary, a silhouette or a shadow edge decided
+by the last bit): at most 10 pixels in a million."""
+import numpy as np
+import pytest
+
+from conftest import sg_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(rt, ctx, w, h, mode):
+    import torch
+    buf = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+    buf8 = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+    ctx.render_rows(h, 0, 1, mode, d_rgb=buf.data_ptr(), d_rgb8=buf8.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return buf, buf8
+
+
+CASES = [("cover", 3840, 2160, 3001), ("cylinders", 3840, 2160, 3001), ("tables", 3840, 2160, 3001),
+         ("reflect_refract", 3840, 2160, 3001), ("glass_spheres", 7680, 4320, 9001), ("groups", 7680, 4320, 30011),
+         ("csg", 7680, 4320, 9001)]
+
+
+@pytest.mark.parametrize("name,w,h,stride", CASES)
+def test_full_size_frame(rt, oracle, gpu_ctx, name, w, h, stride):
+    import torch
+    gpu_ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(w, h).flatten())
+    gpu_ctx.reset_stats()
+    fast, fast8 = _frame(rt, gpu_ctx, w, h, rt.MODE_FAST)
+    st = gpu_ctx.stats()
+    rays = st.primary_rays + st.shadow_rays + st.reflect_rays + st.refract_rays
+    print(f"{name} {w}x{h}: {st.kernel_ms:.2f} ms, {rays / 1e6:.1f} Mrays, {rays / st.kernel_ms / 1e3:.0f} Mrays/s")
+    assert st.primary_rays == w * h and st.csg_overflows == 0
+    assert bool(torch.isfinite(fast).all())
+    # lattice of pixels against the oracle
+    pix = np.arange(stride // 2, w * h, stride, dtype=np.int64)
+    ref, ref8, _ = oracle.OracleScene(sg_path(name)).render_pixels(pix, w, h, threads=8)
+    idx = torch.from_numpy(pix).cuda()
+    got = fast.reshape(-1, 3)[idx].cpu().numpy()
+    got8 = fast8.reshape(-1, 3)[idx].cpu().numpy()
+    assert (np.abs(got - ref).max(axis=1) <= 1e-8).mean() >= 0.999
+    assert (np.abs(got8.astype(int) - ref8.astype(int)).max(axis=1) <= 1).mean() >= 0.999
+    # device quantisation == quantisation of the device's f64 (checked on a band: the host routine is scalar)
+    band = slice(h // 2, h // 2 + 16)
+    assert np.array_equal(fast8[band].cpu().numpy(), rt.quantize(fast[band].cpu().numpy()))
+    # identical when rendered again, and when rendered as two cyclic row parts
+    again, _ = _frame(rt, gpu_ctx, w, h, rt.MODE_FAST)
+    assert torch.equal(again, fast)
+    del again
+    rows0 = gpu_ctx.part_rows(8, 0, 2)
+    part = torch.empty((rows0, w, 3), dtype=torch.float64, device="cuda")
+    gpu_ctx.render_rows(8, 0, 2, rt.MODE_FAST, d_rgb=part.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    tiles = fast[: (h // 16) * 16].reshape(h // 16, 2, 8, w, 3)[:, 0].reshape(-1, w, 3)
+    assert torch.equal(part[: tiles.shape[0]], tiles)
+    del part
+    strict, _ = _frame(rt, gpu_ctx, w, h, rt.MODE_STRICT)
+    off = int(((strict - fast).abs().amax(dim=2) > 1e-8).sum())
+    print(f"  strict vs fast: {off} of {w * h} pixels differ by more than 1e-8")
+    assert off <= 1e-5 * w * h
+    got = strict.reshape(-1, 3)[idx].cpu().numpy()
+    worst = float(np.abs(got - ref).max())
+    assert worst <= 1e-10
+
+
+def test_teapot_room_quarter_frame(rt, oracle, gpu_ctx):
+    """6320 smooth triangles, brute force: the 3840x2160 camera, rows 1000..1015 only (one cyclic part of a
+    135-way split keeps the test at seconds); pixels on a lattice against the oracle."""
+    import torch
+    w, h = 3840, 2160
+    gpu_ctx.upload(rt.Scene.from_sg(sg_path("teapot_room")).set_resolution(w, h).flatten())
+    n_parts, part = 135, 125  # tiles of 16 rows: tile 125 = rows 2000..2015
+    rows = gpu_ctx.part_rows(16, part, n_parts)
+    assert rows == 16
+    buf = torch.empty((rows, w, 3), dtype=torch.float64, device="cuda")
+    gpu_ctx.reset_stats()
+    gpu_ctx.render_rows(16, part, n_parts, rt.MODE_FAST, d_rgb=buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = gpu_ctx.stats()
+    print(f"teapot_room rows 2000-2015 of 2160: {st.kernel_ms:.1f} ms")
+    xs = np.arange(5, w, 97)
+    pix = ((2000 + np.arange(16))[:, None] * w + xs[None, :]).ravel()
+    ref, _, _ = oracle.OracleScene(sg_path("teapot_room")).render_pixels(pix, w, h, threads=8)
+    got = buf[:, torch.from_numpy(xs).cuda()].reshape(-1, 3).cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-8
