@@ -240,6 +240,24 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = upload(ctx, s->csg_roots, (size_t)s->n_csg_roots, &d.csg_roots))) return rc;
     std::vector<DVisit> dv((size_t)s->n_visits);
     std::vector<int32_t> class_mat((size_t)std::max(s->n_classes, 1), 0);
+    double diag_thr = 0.0;
+    auto leaf_record = [&](DVisit& D, int leaf) {
+        const DLeaf& L = dl[leaf];
+        std::memcpy(D.w2o, L.w2o, sizeof D.w2o);
+        if (L.flags & DLEAF_DIAG) {
+            D.w2o[1] = L.inv_diag[0], D.w2o[2] = L.inv_diag[1], D.w2o[4] = L.inv_diag[2];
+            D.w2o[6] = -L.w2o[3] * L.inv_diag[0], D.w2o[8] = -L.w2o[7] * L.inv_diag[1], D.w2o[9] = -L.w2o[11] * L.inv_diag[2];
+            if (L.kind == RTAMD_CUBE)
+                for (int k = 0; k < 3; k++) diag_thr = std::max(diag_thr, 1e-5 * std::fabs(L.inv_diag[k]) * (1.0 + 1e-9));
+        }
+        D.p0 = L.p0, D.p1 = L.p1;
+        if (L.kind == RTAMD_MESH) {
+            int32_t tr[2] = {L.tri_start, L.tri_count};
+            std::memcpy(&D.p0, tr, sizeof tr);
+        }
+        D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
+        D.order_base = L.order_base;
+    };
     for (int i = 0; i < s->n_visits; i++) {
         const rtamd_visit& V = s->visits[i];
         DVisit& D = dv[i];
@@ -249,19 +267,30 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         class_mat[V.eq_class] = V.class_material;
         D.unit = V.unit;
         D.vflags_class = (V.flags & 0xffu) | ((uint32_t)V.eq_class << 8);
-        if (!(V.flags & RTAMD_VISIT_CSG)) {
-            const DLeaf& L = dl[V.unit];
-            std::memcpy(D.w2o, L.w2o, sizeof D.w2o);
-            if (L.flags & DLEAF_DIAG) D.w2o[1] = L.inv_diag[0], D.w2o[2] = L.inv_diag[1], D.w2o[4] = L.inv_diag[2];
-            D.p0 = L.p0, D.p1 = L.p1;
-            if (L.kind == RTAMD_MESH) {
-                int32_t tr[2] = {L.tri_start, L.tri_count};
-                std::memcpy(&D.p0, tr, sizeof tr);
-            }
-            D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
-            D.order_base = L.order_base;
-        }
+        if (!(V.flags & RTAMD_VISIT_CSG)) leaf_record(D, V.unit);
     }
+    // the same units once each, in depth-first order (what traversals without a container pass walk)
+    std::vector<int> root_of((size_t)s->n_leaves, -1);
+    for (int r = 0; r < s->n_csg_roots; r++)
+        for (int l = s->csg_roots[r].leaf_lo; l < s->csg_roots[r].leaf_hi; l++) root_of[l] = r;
+    std::vector<DVisit> dv_dfs;
+    for (int i = 0; i < s->n_leaves; i++) {
+        DVisit D;
+        std::memset(&D, 0, sizeof D);
+        if (root_of[i] < 0) {
+            D.unit = i;
+            D.vflags_class = RTAMD_VISIT_FIRST | ((uint32_t)dl[i].eq_class << 8);
+            leaf_record(D, i);
+        } else {
+            if (i > 0 && root_of[i - 1] == root_of[i]) continue;
+            D.unit = root_of[i];
+            D.vflags_class = RTAMD_VISIT_FIRST | RTAMD_VISIT_CSG;
+        }
+        dv_dfs.push_back(D);
+    }
+    d.n_visits_dfs = (int)dv_dfs.size();
+    d.diag_thr = diag_thr;
+    if ((rc = upload(ctx, dv_dfs.data(), dv_dfs.size(), &d.visits_dfs))) return rc;
     if ((rc = upload(ctx, class_mat.data(), class_mat.size(), &d.class_material))) return rc;
     if ((rc = upload(ctx, dv.data(), dv.size(), &d.visits))) return rc;
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;

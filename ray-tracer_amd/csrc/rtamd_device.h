@@ -26,7 +26,8 @@ struct DLeaf {
 // One step of the traversal order, self-contained for a plain leaf so that one batch of scalar
 // loads brings everything its intersection needs. 128 bytes, 16-byte aligned.
 struct alignas(16) DVisit {
-    double w2o[12];         //   0  DLEAF_DIAG leaves: slots 1, 2, 4 (zeros of the matrix) hold 1/w2o[0], 1/w2o[5], 1/w2o[10]
+    double w2o[12];         //   0  DLEAF_DIAG leaves: slots 1, 2, 4 (zeros of the matrix) hold 1/w2o[0], 1/w2o[5], 1/w2o[10],
+                            //      slots 6, 8, 9 the world-space centre -w2o[3]/w2o[0], -w2o[7]/w2o[5], -w2o[11]/w2o[10]
     double p0, p1;          //  96  cylinder/cone min, max; MESH: the bytes of p0 hold int32 tri_start, tri_count
     uint32_t kind_flags;    // 112  kind | leaf flags << 8
     int32_t order_base;     // 116
@@ -41,7 +42,8 @@ struct DScene {
     int32_t n_visits;
     int32_t n_leaves;
     int32_t ri_safe;  // every refractive index is finite and > 0
-    int32_t pad_;
+    int32_t n_visits_dfs;
+    double diag_thr;  // FAST: smallest |direction component| for which every axis-aligned cube sees |scaled component| >= EPSILON
     const rtamd_light* lights;
     const DLeaf* leaves;
     const double* chain;
@@ -50,7 +52,8 @@ struct DScene {
     const rtamd_material* materials;
     const rtamd_csg_node* csg_nodes;
     const rtamd_csg_root* csg_roots;
-    const DVisit* visits;
+    const DVisit* visits;      // grouped by equality class: the order container passes need
+    const DVisit* visits_dfs;  // one record per plain leaf / top-most CSG object in depth-first order
     const int32_t* class_material;  // material of each equality class
 };
 
