@@ -96,7 +96,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
         for (int c = 0; c < 2; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
-    if ((e = hipMalloc(&ctx->d_queue, 256)) != hipSuccess) return bail("hipMalloc(queue)", e);
+    if ((e = hipMalloc(&ctx->d_queue, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(queue)", e);
     if ((e = hipMalloc(&ctx->d_stats, (size_t)mb * RTAMD_STAT_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(stats)", e);
     if ((e = hipMemset(ctx->d_stats, 0, (size_t)mb * RTAMD_STAT_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
@@ -300,6 +300,23 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     return RTAMD_OK;
 }
 
+// A stride near n / golden ratio that is coprime to n: g -> (g * stride) % n visits every group once,
+// neighbours in the queue far apart in the frame.
+static int64_t coprime_stride(int64_t n) {
+    if (n <= 2) return 1;
+    int64_t s = (int64_t)((double)n * 0.6180339887498949);
+    if (s < 1) s = 1;
+    auto gcd = [](int64_t a, int64_t b) {
+        while (b) {
+            int64_t t = a % b;
+            a = b, b = t;
+        }
+        return a;
+    };
+    while (gcd(s, n) != 1) s++;
+    return s % n == 0 ? 1 : s;
+}
+
 static int64_t part_rows(int vsize, const rtamd_rows* r) {
     if (!r || r->tile_rows <= 0 || r->n_parts <= 0 || r->part < 0 || r->part >= r->n_parts) return -1;
     int64_t rows = 0;
@@ -323,7 +340,9 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     w.total_lanes = ctx->total_lanes;
     int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->has_csg ? 1 : 0], (w.n_pixels + 255) / 256);
     blocks = std::max(blocks, 1);
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, 256, stream));
+    w.n_groups = (w.n_pixels + 63) / 64;
+    w.group_stride = coprime_stride(w.n_groups);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, ctx->has_csg, blocks, stream)
                                              : rtamd_launch_fast(ctx->ds, w, ctx->has_csg, blocks, stream);
@@ -427,8 +446,8 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
     if (getenv("RTAMD_PROFILE_DUMP")) {  // diagnostic builds (-DRTAMD_PROFILE) only
         const unsigned long long* p = slots.data() + ST_COUNT;
         if (p[3])
-            fprintf(stderr, "[rtamd profile] wave-iterations %llu: refill %.0f, traversal %.0f, post %.0f cycles per iteration\n", p[3],
-                    (double)p[0] / p[3], (double)p[1] / p[3], (double)p[2] / p[3]);
+            fprintf(stderr, "[rtamd profile] wave-iterations %llu: refill %.0f, traversal %.0f (record loads %.0f), post %.0f cycles per iteration\n",
+                    p[3], (double)p[0] / p[3], (double)p[1] / p[3], (double)p[4] / p[3], (double)p[2] / p[3]);
     }
     return RTAMD_OK;
 }

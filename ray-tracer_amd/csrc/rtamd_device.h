@@ -73,7 +73,8 @@ enum {
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
 #define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
 #define RTAMD_FRAME_F64 20   // doubles per saved shade-point frame
-#define RTAMD_CHUNK 256      // pixels a wave takes from the queue at a time
+#define RTAMD_QUEUES 64        // counters the work queue is split into
+#define RTAMD_QUEUE_STRIDE 16  // 64-bit words between two counters (128 bytes)
 
 struct DWork {
     // which pixels
@@ -81,11 +82,13 @@ struct DWork {
     int32_t tile_rows, part, n_parts;
     int32_t remaining;          // recursion budget of the primary rays
     int64_t n_pixels;           // pixels of this part (or number of custom rays)
+    int64_t n_groups;           // ceil(n_pixels / 64): the unit of the work queue
+    int64_t group_stride;       // coprime to n_groups: queue position g stands for pixel group (g * stride) % n_groups
     const double* custom_rays;  // NULL: camera rays; else n_pixels x 6
     double* out_rgb;            // may be NULL
     uint8_t* out_rgb8;          // may be NULL
     // scratch the library owns
-    unsigned long long* queue_head;  // next unassigned pixel
+    unsigned long long* queue_head;  // [RTAMD_QUEUES] counters, RTAMD_QUEUE_STRIDE words apart
     unsigned long long* stats;       // [blocks][RTAMD_STAT_STRIDE]: every block adds into its own slot
     double* frames;                  // [max_remaining][RTAMD_FRAME_F64][total_lanes]
     int64_t total_lanes;
