@@ -232,6 +232,53 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     int rc;
     if ((rc = upload(ctx, s->lights, (size_t)s->n_lights, &d.lights))) return rc;
     if ((rc = upload(ctx, dl.data(), dl.size(), &d.leaves))) return rc;
+    std::vector<DShade> sh((size_t)s->n_leaves);
+    for (int i = 0; i < s->n_leaves; i++) {
+        const rtamd_leaf& L = s->leaves[i];
+        DShade& H = sh[i];
+        std::memset(&H, 0, sizeof H);
+        H.kind = L.kind, H.flags = L.flags, H.eq_class = L.eq_class, H.chain_len = L.chain_len, H.chain_start = L.chain_start;
+        H.tri_start = L.tri_start, H.p0 = L.p0, H.p1 = L.p1;
+        std::memcpy(H.chain0, s->chain + (size_t)L.chain_start * 12, sizeof H.chain0);
+        if (L.chain_len > 1) std::memcpy(H.chain1, s->chain + ((size_t)L.chain_start + 1) * 12, sizeof H.chain1);
+        H.mat = s->materials[L.material];
+    }
+    if ((rc = upload(ctx, sh.data(), sh.size(), &d.shade))) return rc;
+    std::vector<double> boxes((size_t)s->n_leaves * 6, 0.0);
+    for (int i = 0; i < s->n_leaves; i++) {
+        const rtamd_leaf& L = s->leaves[i];
+        if (L.kind != RTAMD_MESH) continue;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        // object -> world: inverse of the affine world -> object matrix (bounds only: rounding is covered by the padding)
+        const double* m = L.w2o;
+        const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+        bool finite = std::isfinite(det) && det != 0.0;
+        double inv[9] = {0};
+        if (finite) {
+            inv[0] = (m[5] * m[10] - m[6] * m[9]) / det, inv[1] = (m[2] * m[9] - m[1] * m[10]) / det, inv[2] = (m[1] * m[6] - m[2] * m[5]) / det;
+            inv[3] = (m[6] * m[8] - m[4] * m[10]) / det, inv[4] = (m[0] * m[10] - m[2] * m[8]) / det, inv[5] = (m[2] * m[4] - m[0] * m[6]) / det;
+            inv[6] = (m[4] * m[9] - m[5] * m[8]) / det, inv[7] = (m[1] * m[8] - m[0] * m[9]) / det, inv[8] = (m[0] * m[5] - m[1] * m[4]) / det;
+        }
+        for (int t = L.tri_start; finite && t < L.tri_start + L.tri_count; t++) {
+            const double* g = s->tri_geom + (size_t)t * 9;
+            for (int v = 0; v < 3; v++) {
+                double p[3], w[3];
+                for (int k = 0; k < 3; k++) p[k] = (v == 0 ? g[k] : g[k] + g[3 * v + k]) - m[4 * k + 3];  // p1, p1 + e1, p1 + e2, minus the translation
+                for (int k = 0; k < 3; k++) {
+                    w[k] = inv[3 * k] * p[0] + inv[3 * k + 1] * p[1] + inv[3 * k + 2] * p[2];
+                    if (!std::isfinite(w[k])) finite = false;
+                    lo[k] = std::min(lo[k], w[k]), hi[k] = std::max(hi[k], w[k]);
+                }
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            // generous against rounding in this inverse and in the triangle test; no bound at all for odd data
+            const double pad = finite ? 1e-6 * std::max({hi[k] - lo[k], std::fabs(lo[k]), std::fabs(hi[k]), 1e-30}) : INFINITY;
+            boxes[(size_t)i * 6 + k] = finite ? lo[k] - pad : -INFINITY;
+            boxes[(size_t)i * 6 + 3 + k] = finite ? hi[k] + pad : INFINITY;
+        }
+    }
+    if ((rc = upload(ctx, boxes.data(), boxes.size(), &d.mesh_box))) return rc;
     if ((rc = upload(ctx, s->chain, (size_t)s->n_chain * 12, &d.chain))) return rc;
     if ((rc = upload(ctx, s->tri_geom, (size_t)s->n_tris * 9, &d.tri_geom))) return rc;
     if ((rc = upload(ctx, s->tri_normals, (size_t)s->n_tris * 9, &d.tri_normals))) return rc;
@@ -448,6 +495,10 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
         if (p[3])
             fprintf(stderr, "[rtamd profile] wave-iterations %llu: refill %.0f, traversal %.0f (record loads %.0f), post %.0f cycles per iteration\n",
                     p[3], (double)p[0] / p[3], (double)p[1] / p[3], (double)p[4] / p[3], (double)p[2] / p[3]);
+        const unsigned long long* q = slots.data() + RTAMD_STAT_STRIDE + ST_COUNT;
+        if (p[3] && ctx->stat_blocks > 1)
+            fprintf(stderr, "[rtamd profile]   post: hit/containers %.0f, setup %.0f, lighting %.0f, return %.0f\n", (double)q[0] / p[3],
+                    (double)q[1] / p[3], (double)q[2] / p[3], (double)q[3] / p[3]);
     }
     return RTAMD_OK;
 }

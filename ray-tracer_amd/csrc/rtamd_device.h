@@ -23,6 +23,22 @@ struct DLeaf {
 };
 #define DLEAF_DIAG 0x100u  // device-side flag: the 3x3 part of w2o is diagonal
 
+// Everything shading a hit on one leaf needs, in one record, so that a lane finds it with one level of
+// loads: the leaf's parameters, the first two levels of its transform chain (deeper chains continue in
+// DScene::chain) and a copy of its material. 480 bytes.
+struct alignas(16) DShade {
+    int32_t kind;
+    uint32_t flags;
+    int32_t eq_class;
+    int32_t chain_len;
+    int32_t chain_start;
+    int32_t tri_start;
+    int32_t pad_[2];
+    double p0, p1;
+    double chain0[12], chain1[12];  // chain[chain_start], chain[chain_start + 1] (the second only if chain_len > 1)
+    rtamd_material mat;
+};
+
 // One step of the traversal order, self-contained for a plain leaf so that one batch of scalar
 // loads brings everything its intersection needs. 128 bytes, 16-byte aligned.
 struct alignas(16) DVisit {
@@ -46,8 +62,10 @@ struct DScene {
     double diag_thr;  // FAST: smallest |direction component| for which every axis-aligned cube sees |scaled component| >= EPSILON
     const rtamd_light* lights;
     const DLeaf* leaves;
+    const DShade* shade;  // one per leaf
     const double* chain;
     const double* tri_geom;
+    const double* mesh_box;  // per leaf 6 doubles: enlarged world-space bounds (lo xyz, hi xyz) of a MESH leaf's triangles
     const double* tri_normals;
     const rtamd_material* materials;
     const rtamd_csg_node* csg_nodes;
@@ -72,7 +90,7 @@ enum {
 
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
 #define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
-#define RTAMD_FRAME_F64 20   // doubles per saved shade-point frame
+#define RTAMD_FRAME_F64 22   // doubles per saved shade-point frame
 #define RTAMD_QUEUES 64        // counters the work queue is split into
 #define RTAMD_QUEUE_STRIDE 16  // 64-bit words between two counters (128 bytes)
 

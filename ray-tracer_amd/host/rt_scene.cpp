@@ -13,6 +13,11 @@
 
 namespace rt {
 
+// Triangles per MESH leaf.  The device tests a leaf's triangles only for rays whose line meets the
+// bounds of that leaf, so short runs (consecutive faces of an OBJ file lie close together) let most rays
+// skip most of a mesh.  Must not exceed RTAMD_MAX_MESH_TRIS.
+static constexpr int kMeshLeafTris = 32;
+
 // ------------------------------------------------------------------ patterns / materials
 static bool color_bits_eq(const Color& a, const Color& b) { return std::memcmp(&a, &b, sizeof(Color)) == 0; }
 
@@ -315,7 +320,7 @@ struct Flattener {
                 const Shape* first = leaf_shape.back();
                 bool smooth = (L.flags & RTAMD_LEAF_SMOOTH) != 0;
                 bool shadow = (L.flags & RTAMD_LEAF_SHADOW) != 0;
-                if (L.kind == RTAMD_MESH && L.tri_count < RTAMD_MAX_MESH_TRIS && L.material == mat && smooth == t.is_smooth && shadow == s.shadow() &&
+                if (L.kind == RTAMD_MESH && L.tri_count < kMeshLeafTris && L.material == mat && smooth == t.is_smooth && shadow == s.shadow() &&
                     bits_eq(first->transform(), s.transform()) && leaf_root.back() == root &&
                     first->parent_transforms().size() == s.parent_transforms().size() &&
                     (s.parent_transforms().empty() ||
