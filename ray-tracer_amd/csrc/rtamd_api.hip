@@ -24,6 +24,7 @@ struct rtamd_ctx {
     int num_cus = 0;
     std::string err;
     bool have_scene = false, has_csg = false;
+    int variant = 0;  // kernel variant of the uploaded scene: 0 plain, 1 triangles, 2 CSG
     DScene ds{};
     std::vector<void*> scene_bufs;
     unsigned long long* d_queue = nullptr;
@@ -31,7 +32,7 @@ struct rtamd_ctx {
     double* d_frames = nullptr;
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
-    int max_blocks[2][2] = {{0, 0}, {0, 0}};  // [mode][has_csg]
+    int max_blocks[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [mode][variant]
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -84,16 +85,16 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
-    for (int csg = 0; csg < 2; csg++) {
+    for (int v = 0; v < 3; v++) {
         int b = 0;
-        if ((e = rtamd_occupancy_strict(csg != 0, &b)) != hipSuccess) return bail("occupancy(strict)", e);
-        ctx->max_blocks[RTAMD_MODE_STRICT][csg] = std::max(1, b) * ctx->num_cus;
-        if ((e = rtamd_occupancy_fast(csg != 0, &b)) != hipSuccess) return bail("occupancy(fast)", e);
-        ctx->max_blocks[RTAMD_MODE_FAST][csg] = std::max(1, b) * ctx->num_cus;
+        if ((e = rtamd_occupancy_strict(v, &b)) != hipSuccess) return bail("occupancy(strict)", e);
+        ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, b) * ctx->num_cus;
+        if ((e = rtamd_occupancy_fast(v, &b)) != hipSuccess) return bail("occupancy(fast)", e);
+        ctx->max_blocks[RTAMD_MODE_FAST][v] = std::max(1, b) * ctx->num_cus;
     }
     int mb = 0;
     for (int m = 0; m < 2; m++)
-        for (int c = 0; c < 2; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
+        for (int c = 0; c < 3; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
     if ((e = hipMalloc(&ctx->d_queue, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(queue)", e);
@@ -343,6 +344,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
     ctx->ds = d;
     ctx->has_csg = s->n_csg_roots > 0;
+    ctx->variant = ctx->has_csg ? 2 : (s->n_tris > 0 ? 1 : 0);
     ctx->have_scene = true;
     return RTAMD_OK;
 }
@@ -385,14 +387,14 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     w.stats = ctx->d_stats;
     w.frames = ctx->d_frames;
     w.total_lanes = ctx->total_lanes;
-    int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->has_csg ? 1 : 0], (w.n_pixels + 255) / 256);
+    int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->variant], (w.n_pixels + 255) / 256);
     blocks = std::max(blocks, 1);
     w.n_groups = (w.n_pixels + 63) / 64;
     w.group_stride = coprime_stride(w.n_groups);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
-    hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, ctx->has_csg, blocks, stream)
-                                             : rtamd_launch_fast(ctx->ds, w, ctx->has_csg, blocks, stream);
+    hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, ctx->variant, blocks, stream)
+                                             : rtamd_launch_fast(ctx->ds, w, ctx->variant, blocks, stream);
     if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;

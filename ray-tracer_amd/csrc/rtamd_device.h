@@ -113,7 +113,8 @@ struct DWork {
 };
 
 // Implemented once per arithmetic mode (rtamd_kernels_strict.hip / rtamd_kernels_fast.hip).
-hipError_t rtamd_launch_strict(const DScene& s, const DWork& w, bool has_csg, int blocks, hipStream_t stream);
-hipError_t rtamd_launch_fast(const DScene& s, const DWork& w, bool has_csg, int blocks, hipStream_t stream);
-hipError_t rtamd_occupancy_strict(bool has_csg, int* blocks_per_cu);
-hipError_t rtamd_occupancy_fast(bool has_csg, int* blocks_per_cu);
+// variant: 0 scene without triangles and CSG, 1 with triangles, 2 with CSG
+hipError_t rtamd_launch_strict(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
+hipError_t rtamd_launch_fast(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
+hipError_t rtamd_occupancy_strict(int variant, int* blocks_per_cu);
+hipError_t rtamd_occupancy_fast(int variant, int* blocks_per_cu);
