@@ -336,6 +336,52 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
         dv_dfs.push_back(D);
     }
+    // Runs of MESH records get bounds records in front: one per 8 leaves, one per 64.  A bounds record
+    // carries the union of the bounds below it and the number of records a wave may skip when none of
+    // its rays meets them.  The record that closes an equality class is never skipped.
+    auto with_bounds = [&](const std::vector<DVisit>& in) {
+        auto is_mesh = [&](const DVisit& v) {
+            return !(v.vflags_class & RTAMD_VISIT_CSG) && (v.kind_flags & 0xffu) == RTAMD_MESH && !(v.vflags_class & RTAMD_VISIT_CLASS_END);
+        };
+        auto bounds_record = [&](const std::vector<DVisit>& body) {
+            DVisit B;
+            std::memset(&B, 0, sizeof B);
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (const DVisit& v : body) {
+                const double* b = (v.kind_flags & 0xffu) == DVISIT_BOUNDS ? v.w2o : &boxes[(size_t)v.unit * 6];
+                for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], b[k]), hi[k] = std::max(hi[k], b[3 + k]);
+            }
+            for (int k = 0; k < 3; k++) B.w2o[k] = lo[k], B.w2o[3 + k] = hi[k];
+            B.kind_flags = DVISIT_BOUNDS;
+            B.unit = (int32_t)body.size();
+            return B;
+        };
+        std::vector<DVisit> out;
+        size_t i = 0;
+        while (i < in.size()) {
+            if (!is_mesh(in[i])) {
+                out.push_back(in[i++]);
+                continue;
+            }
+            size_t j = i;
+            while (j < in.size() && is_mesh(in[j])) j++;
+            for (size_t a = i; a < j; a += 64) {  // one outer group
+                std::vector<DVisit> outer;
+                for (size_t b = a; b < std::min(j, a + 64); b += 8) {  // its inner groups
+                    std::vector<DVisit> inner(in.begin() + (long)b, in.begin() + (long)std::min(j, b + 8));
+                    if (inner.size() > 1) outer.push_back(bounds_record(inner));
+                    outer.insert(outer.end(), inner.begin(), inner.end());
+                }
+                if (outer.size() > 9) out.push_back(bounds_record(outer));
+                out.insert(out.end(), outer.begin(), outer.end());
+            }
+            i = j;
+        }
+        return out;
+    };
+    dv_dfs = with_bounds(dv_dfs);
+    dv = with_bounds(dv);
+    d.n_visits = (int)dv.size();
     d.n_visits_dfs = (int)dv_dfs.size();
     d.diag_thr = diag_thr;
     if ((rc = upload(ctx, dv_dfs.data(), dv_dfs.size(), &d.visits_dfs))) return rc;

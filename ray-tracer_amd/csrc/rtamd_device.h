@@ -51,6 +51,8 @@ struct alignas(16) DVisit {
     uint32_t vflags_class;  // 124  RTAMD_VISIT_* | eq_class << 8
 };
 
+#define DVISIT_BOUNDS 6u  // kind of a bounds record: w2o[0..5] = lo xyz, hi xyz (world space); unit = records to skip
+
 struct DScene {
     rtamd_camera cam;
     int32_t max_remaining;
