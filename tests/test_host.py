@@ -322,3 +322,14 @@ def test_bench_flop_model_matches_the_per_scene_constants():
               "teapot_room": 518 - 62 + 33 + 6320 * 51}
     for name, flops in expect.items():
         assert bench.flops_per_ray(sg_path(name)) == flops, name
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
