@@ -134,7 +134,7 @@ class Flat:
         return abi.SceneStruct.from_address(self.view)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _host is not None:  # module globals are gone at interpreter exit
             _host.rth_free_flat(self._h)
             self._h = None
 
@@ -195,7 +195,7 @@ class Scene:
         return (rgb, u8, st) if want_u8 else (rgb, st)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _host is not None:
             _host.rth_free_scene(self._h)
             self._h = None
 
@@ -267,7 +267,7 @@ class Context:
         self._chk(_gpu.rtamd_reset_stats(self._h))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _gpu is not None:
             _gpu.rtamd_ctx_destroy(self._h)
             self._h = None
 

@@ -32,7 +32,7 @@ struct rtamd_ctx {
     double* d_frames = nullptr;
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
-    int max_blocks[2][3] = {{0, 0, 0}, {0, 0, 0}};  // [mode][variant]
+    int max_blocks[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // [mode][variant]
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -85,7 +85,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
-    for (int v = 0; v < 3; v++) {
+    for (int v = 0; v < 4; v++) {
         int b = 0;
         if ((e = rtamd_occupancy_strict(v, &b)) != hipSuccess) return bail("occupancy(strict)", e);
         ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, b) * ctx->num_cus;
@@ -94,7 +94,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     }
     int mb = 0;
     for (int m = 0; m < 2; m++)
-        for (int c = 0; c < 3; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
+        for (int c = 0; c < 4; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
     if ((e = hipMalloc(&ctx->d_queue, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(queue)", e);
@@ -204,12 +204,19 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if (M.pattern_kind < RTAMD_PAT_NONE || M.pattern_kind > RTAMD_PAT_TEST) return fail(ctx, RTAMD_E_INVALID, "pattern kind out of range");
         if (!(std::isfinite(M.refractive_index) && M.refractive_index > 0.0)) ri_safe = false;
     }
+    bool csg_small = true;  // no CSG object can put more than RTAMD_CSG_LIST_SMALL intersections on a ray
     for (int i = 0; i < s->n_csg_roots; i++) {
         const rtamd_csg_root& R = s->csg_roots[i];
         if (R.node_start < 0 || R.node_count < 1 || R.node_start + R.node_count > s->n_csg_nodes || R.leaf_lo < 0 ||
             R.leaf_hi > s->n_leaves || R.leaf_lo > R.leaf_hi)
             return fail(ctx, RTAMD_E_INVALID, "csg root out of range");
         if (R.leaf_hi - R.leaf_lo > RTAMD_MAX_CSG_LEAVES) return fail(ctx, RTAMD_E_LIMIT, "csg object with too many leaves");
+        long long most = 0;  // sphere, cube: 2; plane: 1; cylinder, cone: walls 2 + caps 2; a triangle: 1
+        for (int l = R.leaf_lo; l < R.leaf_hi; l++) {
+            const rtamd_leaf& L = s->leaves[l];
+            most += L.kind == RTAMD_PLANE ? 1 : L.kind == RTAMD_MESH ? L.tri_count : (L.kind == RTAMD_CYLINDER || L.kind == RTAMD_CONE) ? 4 : 2;
+        }
+        if (most > RTAMD_CSG_LIST_SMALL) csg_small = false;
         for (int q = R.node_start; q < R.node_start + R.node_count; q++) {
             const rtamd_csg_node& N = s->csg_nodes[q];
             if (N.op < RTAMD_CSG_UNION || N.op > RTAMD_CSG_DIFFERENCE || N.leaf_lo < R.leaf_lo || N.leaf_hi > R.leaf_hi ||
@@ -390,7 +397,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
     ctx->ds = d;
     ctx->has_csg = s->n_csg_roots > 0;
-    ctx->variant = ctx->has_csg ? 2 : (s->n_tris > 0 ? 1 : 0);
+    ctx->variant = ctx->has_csg ? (csg_small ? 3 : 2) : (s->n_tris > 0 ? 1 : 0);
     ctx->have_scene = true;
     return RTAMD_OK;
 }

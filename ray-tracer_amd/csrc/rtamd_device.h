@@ -90,6 +90,7 @@ enum {
     ST_COUNT
 };
 
+#define RTAMD_CSG_LIST_SMALL 12  // list length of the kernel variant for small CSG objects
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
 #define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
 #define RTAMD_FRAME_F64 22   // doubles per saved shade-point frame
@@ -115,7 +116,8 @@ struct DWork {
 };
 
 // Implemented once per arithmetic mode (rtamd_kernels_strict.hip / rtamd_kernels_fast.hip).
-// variant: 0 scene without triangles and CSG, 1 with triangles, 2 with CSG
+// variant: 0 scene without triangles and CSG, 1 with triangles, 2 with CSG, 3 with CSG objects of at most
+// RTAMD_CSG_LIST_SMALL possible intersections per ray
 hipError_t rtamd_launch_strict(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_launch_fast(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_occupancy_strict(int variant, int* blocks_per_cu);

@@ -201,6 +201,37 @@ def test_color_at_random_rays(rt, oracle, gpu_ctx, name):
         _both(rt, gpu_ctx, o, rays, remaining)
 
 
+def test_nested_csg_with_long_intersection_lists(rt, oracle, gpu_ctx, tmp_path):
+    """A CSG object whose leaves can put 14 intersections on one ray (a cube and three capped cylinders,
+    nested three deep): the library renders it with the long per-ray lists, where the committed csg scene
+    (at most 6 per object) takes the short ones.  Same bar as every other frame."""
+    text = open(sg_path("csg")).read()
+    old = ("node csg mat 3 xf 0 shadow 1 difference\n"
+           "node cube mat 4 xf 0 shadow 1\n"
+           "node cylinder mat 5 xf 0 shadow 1 -2 2 1\n"
+           "node cylinder mat 5 xf 9 shadow 1 -4 4 1\n")
+    new = ("node csg mat 3 xf 0 shadow 1 difference\n"
+           "node cube mat 4 xf 0 shadow 1\n"
+           "node csg mat 3 xf 0 shadow 1 union\n"
+           "node cylinder mat 5 xf 0 shadow 1 -2 2 1\n"
+           "node csg mat 3 xf 0 shadow 1 union\n"
+           "node cylinder mat 5 xf 9 shadow 1 -4 4 1\n"
+           "node cylinder mat 5 xf 4 shadow 1 -6 6 1\n")
+    assert old in text
+    p = str(tmp_path / "nested.sg")
+    with open(p, "w") as f:
+        f.write(text.replace(old, new).replace("objects 9", "objects 8"))
+    w, h = 160, 80
+    ref, ref8, _ = oracle.OracleScene(p).render(w, h, threads=8)
+    gpu_ctx.upload(rt.Scene.from_sg(p).set_resolution(w, h).flatten())
+    for mode, (m, tol) in _modes(rt).items():
+        gpu_ctx.reset_stats()
+        rgb, u8 = gpu_ctx.render(w, h, m, want_u8=True)
+        assert gpu_ctx.stats().csg_overflows == 0
+        assert np.abs(rgb - ref).max() <= tol, mode
+        assert (np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+
+
 # ------------------------------------------------------------------ boundary behaviour
 def test_rows_partition_equals_whole_frame(rt, gpu_ctx):
     """Rendering the frame in parts (what the ranks of a multi-GPU job do) gives the bits of one call."""
