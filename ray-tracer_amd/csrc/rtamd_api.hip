@@ -311,7 +311,6 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             std::memcpy(&D.p0, tr, sizeof tr);
         }
         D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
-        D.order_base = L.order_base;
     };
     for (int i = 0; i < s->n_visits; i++) {
         const rtamd_visit& V = s->visits[i];
@@ -387,6 +386,15 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         return out;
     };
     dv_dfs = with_bounds(dv_dfs);
+    // runs of axis-aligned cubes with the same shadow flag: every record carries the length of the rest of its run
+    for (size_t i = dv_dfs.size(); i-- > 0;) {
+        const uint32_t want = (uint32_t)RTAMD_CUBE | (DLEAF_DIAG << 8), mask = 0xffu | (DLEAF_DIAG << 8);
+        DVisit& D = dv_dfs[i];
+        if ((D.vflags_class & RTAMD_VISIT_CSG) || (D.kind_flags & mask) != want) continue;
+        const bool joins = i + 1 < dv_dfs.size() && dv_dfs[i + 1].run > 0 &&
+                           ((dv_dfs[i + 1].kind_flags ^ D.kind_flags) & (RTAMD_LEAF_SHADOW << 8)) == 0;
+        D.run = joins ? dv_dfs[i + 1].run + 1 : 1;
+    }
     dv = with_bounds(dv);
     d.n_visits = (int)dv.size();
     d.n_visits_dfs = (int)dv_dfs.size();

@@ -46,7 +46,8 @@ struct alignas(16) DVisit {
                             //      slots 6, 8, 9 the world-space centre -w2o[3]/w2o[0], -w2o[7]/w2o[5], -w2o[11]/w2o[10]
     double p0, p1;          //  96  cylinder/cone min, max; MESH: the bytes of p0 hold int32 tri_start, tri_count
     uint32_t kind_flags;    // 112  kind | leaf flags << 8
-    int32_t order_base;     // 116
+    int32_t run;            // 116  depth-first list: records from this one on that are axis-aligned cubes with one shadow
+                            //      flag (0: this record is not such a cube)
     int32_t unit;           // 120  leaf index, or csg root index when the visit has RTAMD_VISIT_CSG
     uint32_t vflags_class;  // 124  RTAMD_VISIT_* | eq_class << 8
 };
