@@ -399,6 +399,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     d.n_visits = (int)dv.size();
     d.n_visits_dfs = (int)dv_dfs.size();
     d.diag_thr = diag_thr;
+    dv_dfs.push_back(DVisit{});  // spare record: the loop over a run of cubes reads one record past the run
     if ((rc = upload(ctx, dv_dfs.data(), dv_dfs.size(), &d.visits_dfs))) return rc;
     if ((rc = upload(ctx, class_mat.data(), class_mat.size(), &d.class_material))) return rc;
     if ((rc = upload(ctx, dv.data(), dv.size(), &d.visits))) return rc;
