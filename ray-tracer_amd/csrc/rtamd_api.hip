@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,14 @@ struct rtamd_ctx {
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // Pixels that may be costly: the screen rectangles (x0, x1, y0, y1, inclusive) around every leaf that is
+    // both reflective and transparent -- each hit on one owes two children, so its pixels run the longest
+    // chains of dependent rays.  Their groups go to the front of the work queue.
+    std::vector<std::array<int, 4>> costly;
+    int32_t* d_order = nullptr;  // queue position -> group of 64 pixels, for the partition of the frame in order_key
+    size_t order_cap = 0;
+    std::array<int64_t, 5> order_key{{-1, -1, -1, -1, -1}};
+    bool order_used = false;
 };
 
 static std::string g_create_err;
@@ -120,6 +129,7 @@ void rtamd_ctx_destroy(rtamd_ctx* ctx) {
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -404,6 +414,76 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = upload(ctx, class_mat.data(), class_mat.size(), &d.class_material))) return rc;
     if ((rc = upload(ctx, dv.data(), dv.size(), &d.visits))) return rc;
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
+    // ---- where on the screen the costly leaves are (empty list: no preference)
+    ctx->costly.clear();
+    ctx->order_key = {{-1, -1, -1, -1, -1}};
+    {
+        const rtamd_camera& C = s->camera;
+        const double* ci = C.inv;  // camera -> world; its inverse takes a world point to the camera's frame
+        const double cdet = ci[0] * (ci[5] * ci[10] - ci[6] * ci[9]) - ci[1] * (ci[4] * ci[10] - ci[6] * ci[8]) + ci[2] * (ci[4] * ci[9] - ci[5] * ci[8]);
+        double w2c[9] = {0};
+        bool usable = std::isfinite(cdet) && cdet != 0.0;
+        if (usable) {
+            w2c[0] = (ci[5] * ci[10] - ci[6] * ci[9]) / cdet, w2c[1] = (ci[2] * ci[9] - ci[1] * ci[10]) / cdet, w2c[2] = (ci[1] * ci[6] - ci[2] * ci[5]) / cdet;
+            w2c[3] = (ci[6] * ci[8] - ci[4] * ci[10]) / cdet, w2c[4] = (ci[0] * ci[10] - ci[2] * ci[8]) / cdet, w2c[5] = (ci[2] * ci[4] - ci[0] * ci[6]) / cdet;
+            w2c[6] = (ci[4] * ci[9] - ci[5] * ci[8]) / cdet, w2c[7] = (ci[1] * ci[8] - ci[0] * ci[9]) / cdet, w2c[8] = (ci[0] * ci[5] - ci[1] * ci[4]) / cdet;
+        }
+        for (int i = 0; usable && i < s->n_leaves; i++) {
+            const rtamd_leaf& L = s->leaves[i];
+            const rtamd_material& M = s->materials[L.material];
+            if (M.reflective == 0.0 || M.transparency == 0.0) continue;
+            // bounds in object space; an unbounded shape makes the whole screen costly, i.e. nothing is preferred
+            double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+            if (L.kind == RTAMD_PLANE) {
+                usable = false;
+            } else if (L.kind == RTAMD_CYLINDER || L.kind == RTAMD_CONE) {
+                if (!std::isfinite(L.p0) || !std::isfinite(L.p1)) usable = false;
+                lo[1] = L.p0, hi[1] = L.p1;
+                if (L.kind == RTAMD_CONE) lo[0] = lo[2] = -std::max(std::fabs(L.p0), std::fabs(L.p1)), hi[0] = hi[2] = -lo[0];
+            } else if (L.kind == RTAMD_MESH) {
+                for (int k = 0; k < 3; k++) lo[k] = INFINITY, hi[k] = -INFINITY;
+                for (int t = L.tri_start; t < L.tri_start + L.tri_count; t++) {
+                    const double* g = s->tri_geom + (size_t)t * 9;
+                    for (int v = 0; v < 3; v++)
+                        for (int k = 0; k < 3; k++) {
+                            const double c = v == 0 ? g[k] : g[k] + g[3 * v + k];
+                            lo[k] = std::min(lo[k], c), hi[k] = std::max(hi[k], c);
+                        }
+                }
+            }
+            if (!usable) break;
+            const double* m = L.w2o;
+            const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+            if (!std::isfinite(det) || det == 0.0) {
+                usable = false;
+                break;
+            }
+            double o2w[9];
+            o2w[0] = (m[5] * m[10] - m[6] * m[9]) / det, o2w[1] = (m[2] * m[9] - m[1] * m[10]) / det, o2w[2] = (m[1] * m[6] - m[2] * m[5]) / det;
+            o2w[3] = (m[6] * m[8] - m[4] * m[10]) / det, o2w[4] = (m[0] * m[10] - m[2] * m[8]) / det, o2w[5] = (m[2] * m[4] - m[0] * m[6]) / det;
+            o2w[6] = (m[4] * m[9] - m[5] * m[8]) / det, o2w[7] = (m[1] * m[8] - m[0] * m[9]) / det, o2w[8] = (m[0] * m[5] - m[1] * m[4]) / det;
+            double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+            for (int corner = 0; corner < 8 && usable; corner++) {
+                double po[3], pw[3], pc[3];
+                for (int k = 0; k < 3; k++) po[k] = ((corner >> k) & 1 ? hi[k] : lo[k]) - m[4 * k + 3];
+                for (int k = 0; k < 3; k++) pw[k] = o2w[3 * k] * po[0] + o2w[3 * k + 1] * po[1] + o2w[3 * k + 2] * po[2] - ci[4 * k + 3];
+                for (int k = 0; k < 3; k++) pc[k] = w2c[3 * k] * pw[0] + w2c[3 * k + 1] * pw[1] + w2c[3 * k + 2] * pw[2];
+                if (!(pc[2] < -1e-9)) {  // at or behind the camera: no rectangle bounds it
+                    usable = false;
+                    break;
+                }
+                const double px = (C.half_width - pc[0] / -pc[2]) / C.pixel_size, py = (C.half_height - pc[1] / -pc[2]) / C.pixel_size;
+                if (!std::isfinite(px) || !std::isfinite(py)) usable = false;
+                x0 = std::min(x0, px), x1 = std::max(x1, px), y0 = std::min(y0, py), y1 = std::max(y1, py);
+            }
+            if (!usable) break;
+            auto pix = [](double v, int n) { return (int)std::min<double>(std::max<double>(v, -1.0), (double)n); };
+            std::array<int, 4> r{{pix(std::floor(x0) - 1, C.hsize), pix(std::ceil(x1) + 1, C.hsize), pix(std::floor(y0) - 1, C.vsize),
+                                  pix(std::ceil(y1) + 1, C.vsize)}};
+            if (r[1] >= 0 && r[0] < C.hsize && r[3] >= 0 && r[2] < C.vsize) ctx->costly.push_back(r);
+        }
+        if (!usable) ctx->costly.clear();
+    }
     ctx->ds = d;
     ctx->has_csg = s->n_csg_roots > 0;
     ctx->variant = ctx->has_csg ? (csg_small ? 3 : 2) : (s->n_tris > 0 ? 1 : 0);
@@ -458,6 +538,44 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     blocks = std::max(blocks, 1);
     w.n_groups = (w.n_pixels + 63) / 64;
     w.group_stride = coprime_stride(w.n_groups);
+    w.order = nullptr;
+    if (!w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
+        // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
+        // The table depends on the partition of the frame only: it is kept until that changes.
+        const std::array<int64_t, 5> key{{w.hsize, w.vsize, w.tile_rows, w.part, w.n_parts}};
+        if (key != ctx->order_key) {
+            ctx->order_used = false;
+            std::vector<int32_t> first, rest;
+            first.reserve((size_t)w.n_groups), rest.reserve((size_t)w.n_groups);
+            for (int64_t j = 0; j < w.n_groups; j++) {
+                const int64_t grp = (j * w.group_stride) % w.n_groups;
+                const int64_t p0 = grp * 64, p1 = std::min<int64_t>(p0 + 63, w.n_pixels - 1);
+                bool hot = false;
+                for (int64_t lrow = p0 / w.hsize; lrow <= p1 / w.hsize && !hot; lrow++) {
+                    const int64_t tile = lrow / w.tile_rows;
+                    const int64_t py = (tile * w.n_parts + w.part) * w.tile_rows + (lrow - tile * w.tile_rows);
+                    const int64_t xa = std::max<int64_t>(p0 - lrow * w.hsize, 0), xb = std::min<int64_t>(p1 - lrow * w.hsize, w.hsize - 1);
+                    for (const auto& r : ctx->costly) hot |= py >= r[2] && py <= r[3] && xb >= r[0] && xa <= r[1];
+                }
+                (hot ? first : rest).push_back((int32_t)grp);
+            }
+            if (!first.empty() && !rest.empty()) {
+                first.insert(first.end(), rest.begin(), rest.end());
+                if (first.size() > ctx->order_cap) {
+                    HIPCHK(ctx, hipDeviceSynchronize());
+                    if (ctx->d_order) HIPCHK(ctx, hipFree(ctx->d_order));
+                    ctx->d_order = nullptr, ctx->order_cap = 0;
+                    HIPCHK(ctx, hipMalloc(&ctx->d_order, first.size() * sizeof(int32_t)));
+                    ctx->order_cap = first.size();
+                }
+                HIPCHK(ctx, hipDeviceSynchronize());  // an earlier launch may still read the table
+                HIPCHK(ctx, hipMemcpy(ctx->d_order, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                ctx->order_used = true;
+            }
+            ctx->order_key = key;
+        }
+        if (ctx->order_used) w.order = ctx->d_order;
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, ctx->variant, blocks, stream)

@@ -107,6 +107,7 @@ struct DWork {
     int64_t n_groups;           // ceil(n_pixels / 64): the unit of the work queue
     int64_t group_stride;       // coprime to n_groups: queue position g stands for pixel group (g * stride) % n_groups
     const double* custom_rays;  // NULL: camera rays; else n_pixels x 6
+    const int32_t* order;       // NULL: groups in strided order; else queue position -> group of 64 pixels
     double* out_rgb;            // may be NULL
     uint8_t* out_rgb8;          // may be NULL
     // scratch the library owns
