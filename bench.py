@@ -99,9 +99,9 @@ def main():
     frame = fg.frame
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
+    def step():  # frame k's rows travel to rank 0 while frame k + 1 renders (rows.FrameGather.exchange)
         ctx.render_rows(R, rank, world, mode, d_rgb=fg.local.data_ptr(), stream=stream)
-        fg.gather()
+        fg.exchange()
 
     def sync():
         if world > 1:
@@ -110,6 +110,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    fg.finish()
     sync()
     ctx.reset_stats()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -119,7 +120,8 @@ def main():
         ev[k][0].record()  # events bracket the render kernel itself, on the stream it is launched on
         ctx.render_rows(R, rank, world, mode, d_rgb=fg.local.data_ptr(), stream=stream)
         ev[k][1].record()
-        fg.gather()
+        fg.exchange()
+    fg.finish()  # the last frame is complete on rank 0 inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()

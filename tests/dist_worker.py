@@ -30,8 +30,21 @@ def main():
         pix = (mine[:, None] * w + np.arange(w)[None, :]).ravel()
         rgb, _, _ = o.render_pixels(pix, w, h)
         fg.local[: len(mine)] = torch.from_numpy(rgb.reshape(len(mine), w, 3))
-    for _ in range(2):  # the exchange is repeatable (bench.py calls it every step)
+    for _ in range(2):  # the exchange is repeatable
         frame = fg.gather()
+    # the pipelined form bench.py uses: frame k travels while frame k + 1 is produced (here: frame + k)
+    mine_rows = fg.local[: len(mine)].clone()
+    first = frame.clone() if rank == 0 else None
+    for k in range(1, 4):
+        fg.local.fill_(float("nan"))
+        fg.local[: len(mine)] = mine_rows + k
+        fg.exchange()
+        if rank == 0 and k > 1:  # the frame submitted one call earlier is complete now
+            assert torch.equal(fg.frame, first + (k - 1)), k
+    frame = fg.finish()
+    if rank == 0:
+        assert torch.equal(frame, first + 3)
+        frame = first
     dist.barrier()
     if rank == 0:
         np.save(out, frame.numpy())
