@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <array>
 #include <string>
@@ -354,11 +355,19 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     }
     // Runs of MESH records get bounds records in front: one per 8 leaves, one per 64.  A bounds record
     // carries the union of the bounds below it and the number of records a wave may skip when none of
-    // its rays meets them.  The record that closes an equality class is never skipped.
+    // its rays meets them.  A record that closes an equality class is skipped only when it is that whole class.
     auto with_bounds = [&](const std::vector<DVisit>& in) {
-        auto is_mesh = [&](const DVisit& v) {
-            return !(v.vflags_class & RTAMD_VISIT_CSG) && (v.kind_flags & 0xffu) == RTAMD_MESH && !(v.vflags_class & RTAMD_VISIT_CLASS_END);
-        };
+        // A record that closes a class may be skipped only when it is the whole class (the record before it
+        // closed the previous one): the container pass then has nothing pending when it is passed over.
+        std::vector<char> groupable(in.size(), 0);
+        for (size_t i = 0; i < in.size(); i++) {
+            const DVisit& v = in[i];
+            const bool mesh = !(v.vflags_class & RTAMD_VISIT_CSG) && (v.kind_flags & 0xffu) == RTAMD_MESH;
+            const bool closes = (v.vflags_class & RTAMD_VISIT_CLASS_END) != 0;
+            const bool alone = closes && (i == 0 || (in[i - 1].vflags_class & RTAMD_VISIT_CLASS_END));
+            groupable[i] = mesh && (!closes || alone);
+        }
+        auto is_mesh = [&](const DVisit& v) { return groupable[(size_t)(&v - in.data())] != 0; };
         auto bounds_record = [&](const std::vector<DVisit>& body) {
             DVisit B;
             std::memset(&B, 0, sizeof B);
@@ -539,6 +548,8 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     w.n_groups = (w.n_pixels + 63) / 64;
     w.group_stride = coprime_stride(w.n_groups);
     w.order = nullptr;
+    w.mesh_few = 8;
+    if (const char* e = getenv("RTAMD_MESH_FEW")) w.mesh_few = atoi(e);  // diagnostic: 0 = always the loop, 64 = never
     if (!w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
         // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
         // The table depends on the partition of the frame only: it is kept until that changes.
@@ -686,6 +697,11 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
         if (p[3] && ctx->stat_blocks > 1)
             fprintf(stderr, "[rtamd profile]   post: hit/containers %.0f, setup %.0f, lighting %.0f, return %.0f\n", (double)q[0] / p[3],
                     (double)q[1] / p[3], (double)q[2] / p[3], (double)q[3] / p[3]);
+        if (p[3] && ctx->stat_blocks > 1 && q[4])
+            fprintf(stderr, "[rtamd profile]   traversals with a container pass pending: %llu (%.1f %%), %.0f cycles each; the others %.0f\n", q[4],
+                    100.0 * q[4] / p[3], (double)q[5] / q[4], (double)(p[1] - q[5]) / (double)(p[3] - q[4]));
+        if (p[3] && ctx->stat_blocks > 1)
+            fprintf(stderr, "[rtamd profile]   most iterations in one wave %llu, longest-running wave %llu cycles\n", q[6], q[7]);
     }
     return RTAMD_OK;
 }
