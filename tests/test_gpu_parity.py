@@ -232,6 +232,24 @@ def test_nested_csg_with_long_intersection_lists(rt, oracle, gpu_ctx, tmp_path):
         assert (np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2) <= 1).mean() >= 0.999
 
 
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_both_forms_of_the_triangle_test_give_the_same_bits(rt, gpu_ctx, mode):
+    """A run of triangles is tested by a loop over its triangles (every lane its own ray) or, when few rays of a
+    wave come near it, one triangle per lane.  Which one runs depends on the company a ray is traced in, so the
+    two must agree to the bit (RTAMD_MESH_FEW is the diagnostic switch: 0 = always the loop, 64 = never)."""
+    w, h = 160, 80
+    _upload(rt, gpu_ctx, "teapot_lowres_room", w, h)
+    m, _ = _modes(rt)[mode]
+    frames = []
+    try:
+        for few in ("0", "64", "3"):
+            os.environ["RTAMD_MESH_FEW"] = few
+            frames.append(gpu_ctx.render(w, h, m))
+    finally:
+        os.environ.pop("RTAMD_MESH_FEW", None)
+    assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
+
+
 # ------------------------------------------------------------------ boundary behaviour
 def test_rows_partition_equals_whole_frame(rt, gpu_ctx):
     """Rendering the frame in parts (what the ranks of a multi-GPU job do) gives the bits of one call."""
