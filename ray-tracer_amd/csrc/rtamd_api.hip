@@ -548,7 +548,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     w.n_groups = (w.n_pixels + 63) / 64;
     w.group_stride = coprime_stride(w.n_groups);
     w.order = nullptr;
-    w.mesh_few = 8;
+    w.mesh_few = 16;
     if (const char* e = getenv("RTAMD_MESH_FEW")) w.mesh_few = atoi(e);  // diagnostic: 0 = always the loop, 64 = never
     if (!w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
         // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
