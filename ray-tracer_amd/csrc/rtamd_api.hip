@@ -320,6 +320,10 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if (L.kind == RTAMD_MESH) {
             int32_t tr[2] = {L.tri_start, L.tri_count};
             std::memcpy(&D.p0, tr, sizeof tr);
+            // the traversal needs the bounds for every run and the matrix only for the runs a ray comes near:
+            // the bounds take the matrix's place in the record, the matrix stays in the leaf table
+            std::memcpy(D.w2o, &boxes[(size_t)leaf * 6], 6 * sizeof(double));
+            for (int k = 6; k < 12; k++) D.w2o[k] = 0.0;
         }
         D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
     };

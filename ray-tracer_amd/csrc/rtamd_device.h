@@ -44,7 +44,8 @@ struct alignas(16) DShade {
 struct alignas(16) DVisit {
     double w2o[12];         //   0  DLEAF_DIAG leaves: slots 1, 2, 4 (zeros of the matrix) hold 1/w2o[0], 1/w2o[5], 1/w2o[10],
                             //      slots 6, 8, 9 the world-space centre -w2o[3]/w2o[0], -w2o[7]/w2o[5], -w2o[11]/w2o[10]
-    double p0, p1;          //  96  cylinder/cone min, max; MESH: the bytes of p0 hold int32 tri_start, tri_count
+    double p0, p1;          //  96  cylinder/cone min, max; MESH: the bytes of p0 hold int32 tri_start, tri_count, and
+                            //      w2o[0..5] hold the run's world-space bounds (lo xyz, hi xyz) instead of the matrix
     uint32_t kind_flags;    // 112  kind | leaf flags << 8
     int32_t run;            // 116  depth-first list: records from this one on that are axis-aligned cubes with one shadow
                             //      flag (0: this record is not such a cube)
