@@ -16,7 +16,7 @@ namespace rt {
 // Triangles per MESH leaf.  The device tests a leaf's triangles only for rays whose line meets the
 // bounds of that leaf, so short runs (consecutive faces of an OBJ file lie close together) let most rays
 // skip most of a mesh.  Must not exceed RTAMD_MAX_MESH_TRIS.
-static constexpr int kMeshLeafTris = 32;
+static constexpr int kMeshLeafTris = 64;
 
 // ------------------------------------------------------------------ patterns / materials
 static bool color_bits_eq(const Color& a, const Color& b) { return std::memcmp(&a, &b, sizeof(Color)) == 0; }
