@@ -26,7 +26,7 @@ struct rtamd_ctx {
     int num_cus = 0;
     std::string err;
     bool have_scene = false, has_csg = false;
-    int variant = 0;  // kernel variant of the uploaded scene: base (0 plain, 1 triangles, 2 CSG, 3 small CSG) + 4 with axis-aligned cubes + 8 with cylinders or cones
+    int variant = 0;  // kernel variant of the uploaded scene: base (0 plain, 1 triangles, 2 CSG, 3 small CSG) + 4 with axis-aligned cubes + 8 with cylinders or cones + 16 with bounds records
     DScene ds{};
     std::vector<void*> scene_bufs;
     unsigned long long* d_queue = nullptr;
@@ -34,7 +34,7 @@ struct rtamd_ctx {
     double* d_frames = nullptr;
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
-    int max_blocks[2][16] = {};  // [mode][variant]
+    int max_blocks[2][32] = {};  // [mode][variant]
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -95,7 +95,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
-    for (int v = 0; v < 16; v++) {
+    for (int v = 0; v < 32; v++) {
         int b = 0;
         if ((e = rtamd_occupancy_strict(v, &b)) != hipSuccess) return bail("occupancy(strict)", e);
         ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, b) * ctx->num_cus;
@@ -104,7 +104,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     }
     int mb = 0;
     for (int m = 0; m < 2; m++)
-        for (int c = 0; c < 16; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
+        for (int c = 0; c < 32; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
     if ((e = hipMalloc(&ctx->d_queue, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(queue)", e);
@@ -263,10 +263,12 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         H.mat = s->materials[L.material];
     }
     if ((rc = upload(ctx, sh.data(), sh.size(), &d.shade))) return rc;
+    // World-space bounds of every leaf that has any (not planes, not cylinders or cones without ends), a little
+    // enlarged.  They are only ever used to pass over leaves no ray of a wave can meet.
     std::vector<double> boxes((size_t)s->n_leaves * 6, 0.0);
+    std::vector<char> bounded((size_t)s->n_leaves, 0);
     for (int i = 0; i < s->n_leaves; i++) {
         const rtamd_leaf& L = s->leaves[i];
-        if (L.kind != RTAMD_MESH) continue;
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         // object -> world: inverse of the affine world -> object matrix (bounds only: rounding is covered by the padding)
         const double* m = L.w2o;
@@ -278,18 +280,42 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             inv[3] = (m[6] * m[8] - m[4] * m[10]) / det, inv[4] = (m[0] * m[10] - m[2] * m[8]) / det, inv[5] = (m[2] * m[4] - m[0] * m[6]) / det;
             inv[6] = (m[4] * m[9] - m[5] * m[8]) / det, inv[7] = (m[1] * m[8] - m[0] * m[9]) / det, inv[8] = (m[0] * m[5] - m[1] * m[4]) / det;
         }
-        for (int t = L.tri_start; finite && t < L.tri_start + L.tri_count; t++) {
-            const double* g = s->tri_geom + (size_t)t * 9;
-            for (int v = 0; v < 3; v++) {
-                double p[3], w[3];
-                for (int k = 0; k < 3; k++) p[k] = (v == 0 ? g[k] : g[k] + g[3 * v + k]) - m[4 * k + 3];  // p1, p1 + e1, p1 + e2, minus the translation
-                for (int k = 0; k < 3; k++) {
-                    w[k] = inv[3 * k] * p[0] + inv[3 * k + 1] * p[1] + inv[3 * k + 2] * p[2];
-                    if (!std::isfinite(w[k])) finite = false;
-                    lo[k] = std::min(lo[k], w[k]), hi[k] = std::max(hi[k], w[k]);
+        auto add_point = [&](const double* q) {  // an object-space point
+            double p[3], w[3];
+            for (int k = 0; k < 3; k++) p[k] = q[k] - m[4 * k + 3];  // minus the translation
+            for (int k = 0; k < 3; k++) {
+                w[k] = inv[3 * k] * p[0] + inv[3 * k + 1] * p[1] + inv[3 * k + 2] * p[2];
+                if (!std::isfinite(w[k])) finite = false;
+                lo[k] = std::min(lo[k], w[k]), hi[k] = std::max(hi[k], w[k]);
+            }
+        };
+        if (L.kind == RTAMD_MESH) {
+            for (int t = L.tri_start; finite && t < L.tri_start + L.tri_count; t++) {
+                const double* g = s->tri_geom + (size_t)t * 9;
+                for (int v = 0; v < 3; v++) {
+                    double q[3];
+                    for (int k = 0; k < 3; k++) q[k] = v == 0 ? g[k] : g[k] + g[3 * v + k];  // p1, p1 + e1, p1 + e2
+                    add_point(q);
                 }
             }
+        } else {
+            double olo[3] = {-1, -1, -1}, ohi[3] = {1, 1, 1};  // sphere, cube
+            if (L.kind == RTAMD_PLANE) finite = false;
+            // A ray nearly parallel to a cone's side gets one intersection that the reference does not check
+            // against the cone's ends (src/shapes/cone.rs:62-70): it may lie anywhere, so a cone has no bounds.
+            if (L.kind == RTAMD_CONE) finite = false;
+            if (L.kind == RTAMD_CYLINDER || L.kind == RTAMD_CONE) {
+                if (!std::isfinite(L.p0) || !std::isfinite(L.p1)) finite = false;
+                olo[1] = L.p0, ohi[1] = L.p1;
+                if (L.kind == RTAMD_CONE) ohi[0] = ohi[2] = std::max(std::fabs(L.p0), std::fabs(L.p1)), olo[0] = olo[2] = -ohi[0];
+            }
+            for (int corner = 0; finite && corner < 8; corner++) {
+                double q[3];
+                for (int k = 0; k < 3; k++) q[k] = (corner >> k) & 1 ? ohi[k] : olo[k];
+                add_point(q);
+            }
         }
+        bounded[(size_t)i] = finite && L.kind != RTAMD_MESH;  // runs of triangles carry their bounds themselves
         for (int k = 0; k < 3; k++) {
             // generous against rounding in this inverse and in the triangle test; no bound at all for odd data
             const double pad = finite ? 1e-6 * std::max({hi[k] - lo[k], std::fabs(lo[k]), std::fabs(hi[k]), 1e-30}) : INFINITY;
@@ -357,7 +383,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
         dv_dfs.push_back(D);
     }
-    // Runs of MESH records get bounds records in front: one per 8 leaves, one per 64.  A bounds record
+    // Runs of records of bounded leaves get bounds records in front: one per 8 leaves, one per 64.  A bounds record
     // carries the union of the bounds below it and the number of records a wave may skip when none of
     // its rays meets them.  A record that closes an equality class is skipped only when it is that whole class.
     auto with_bounds = [&](const std::vector<DVisit>& in) {
@@ -366,7 +392,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         std::vector<char> groupable(in.size(), 0);
         for (size_t i = 0; i < in.size(); i++) {
             const DVisit& v = in[i];
-            const bool mesh = !(v.vflags_class & RTAMD_VISIT_CSG) && (v.kind_flags & 0xffu) == RTAMD_MESH;
+            const bool mesh = !(v.vflags_class & RTAMD_VISIT_CSG) && ((v.kind_flags & 0xffu) == RTAMD_MESH || bounded[(size_t)v.unit]);
             const bool closes = (v.vflags_class & RTAMD_VISIT_CLASS_END) != 0;
             const bool alone = closes && (i == 0 || (in[i - 1].vflags_class & RTAMD_VISIT_CLASS_END));
             groupable[i] = mesh && (!closes || alone);
@@ -385,6 +411,21 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             B.unit = (int32_t)body.size();
             return B;
         };
+        // A bounds record costs about as much as two tests of an axis-aligned cube; it is worth having when
+        // what it can save is several times that.  Rough costs in instructions per wave.
+        const double kBoundsCost = 45.0, kWorthIt = 10.0;
+        auto cost = [&](const DVisit& v) {
+            const uint32_t kind = v.kind_flags & 0xffu;
+            if (kind == DVISIT_BOUNDS) return 0.0;
+            if (kind == RTAMD_MESH) return 150.0;
+            if (kind == RTAMD_CUBE && ((v.kind_flags >> 8) & DLEAF_DIAG)) return 25.0;
+            return 120.0;
+        };
+        auto total = [&](const std::vector<DVisit>& body) {
+            double c = 0.0;
+            for (const DVisit& v : body) c += cost(v);
+            return c;
+        };
         std::vector<DVisit> out;
         size_t i = 0;
         while (i < in.size()) {
@@ -396,12 +437,14 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             while (j < in.size() && is_mesh(in[j])) j++;
             for (size_t a = i; a < j; a += 64) {  // one outer group
                 std::vector<DVisit> outer;
+                size_t inner_bounds = 0;
                 for (size_t b = a; b < std::min(j, a + 64); b += 8) {  // its inner groups
                     std::vector<DVisit> inner(in.begin() + (long)b, in.begin() + (long)std::min(j, b + 8));
-                    if (inner.size() > 1) outer.push_back(bounds_record(inner));
+                    if (inner.size() > 1 && total(inner) >= kWorthIt * kBoundsCost) outer.push_back(bounds_record(inner)), inner_bounds++;
                     outer.insert(outer.end(), inner.begin(), inner.end());
                 }
-                if (outer.size() > 9) out.push_back(bounds_record(outer));
+                const size_t leaves_in = outer.size() - inner_bounds;
+                if (leaves_in > 1 && total(outer) >= kWorthIt * kBoundsCost && !(inner_bounds == 1 && leaves_in <= 8)) out.push_back(bounds_record(outer));
                 out.insert(out.end(), outer.begin(), outer.end());
             }
             i = j;
@@ -499,12 +542,18 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     }
     ctx->ds = d;
     ctx->has_csg = s->n_csg_roots > 0;
+    bool has_bounds = false;
     ctx->variant = ctx->has_csg ? (csg_small ? 3 : 2) : (s->n_tris > 0 ? 1 : 0);
     if (!ctx->has_csg)  // the CSG kernels are built without the slab code
         for (int i = 0; i < s->n_leaves; i++) {
             if (dl[i].kind == RTAMD_CUBE && (dl[i].flags & DLEAF_DIAG)) ctx->variant |= 4;
             if (dl[i].kind == RTAMD_CYLINDER || dl[i].kind == RTAMD_CONE) ctx->variant |= 8;
         }
+    if (!ctx->has_csg) {
+        for (const DVisit& v : dv) has_bounds |= (v.kind_flags & 0xffu) == DVISIT_BOUNDS;
+        for (const DVisit& v : dv_dfs) has_bounds |= (v.kind_flags & 0xffu) == DVISIT_BOUNDS;
+        if (has_bounds) ctx->variant |= 16;
+    }
     ctx->have_scene = true;
     return RTAMD_OK;
 }

@@ -122,7 +122,7 @@ struct DWork {
 // Implemented once per arithmetic mode (rtamd_kernels_strict.hip / rtamd_kernels_fast.hip).
 // variant: base (0 scene without triangles and CSG, 1 with triangles, 2 with CSG, 3 with CSG objects of at most
 // RTAMD_CSG_LIST_SMALL possible intersections per ray) + 4 if there are axis-aligned cubes outside CSG objects
-// + 8 if there are cylinders or cones (bases 2 and 3 ignore both)
+// + 8 if there are cylinders or cones + 16 if the visit lists hold bounds records (bases 2 and 3 ignore all three)
 hipError_t rtamd_launch_strict(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_launch_fast(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_occupancy_strict(int variant, int* blocks_per_cu);
