@@ -266,7 +266,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     // World-space bounds of every leaf that has any (not planes, not cylinders or cones without ends), a little
     // enlarged.  They are only ever used to pass over leaves no ray of a wave can meet.
     std::vector<double> boxes((size_t)s->n_leaves * 6, 0.0);
-    std::vector<char> bounded((size_t)s->n_leaves, 0);
+    std::vector<char> bounded((size_t)s->n_leaves, 0), has_box((size_t)s->n_leaves, 0);
     for (int i = 0; i < s->n_leaves; i++) {
         const rtamd_leaf& L = s->leaves[i];
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -301,9 +301,6 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         } else {
             double olo[3] = {-1, -1, -1}, ohi[3] = {1, 1, 1};  // sphere, cube
             if (L.kind == RTAMD_PLANE) finite = false;
-            // A ray nearly parallel to a cone's side gets one intersection that the reference does not check
-            // against the cone's ends (src/shapes/cone.rs:62-70): it may lie anywhere, so a cone has no bounds.
-            if (L.kind == RTAMD_CONE) finite = false;
             if (L.kind == RTAMD_CYLINDER || L.kind == RTAMD_CONE) {
                 if (!std::isfinite(L.p0) || !std::isfinite(L.p1)) finite = false;
                 olo[1] = L.p0, ohi[1] = L.p1;
@@ -315,7 +312,11 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 add_point(q);
             }
         }
-        bounded[(size_t)i] = finite && L.kind != RTAMD_MESH;  // runs of triangles carry their bounds themselves
+        // Runs of triangles carry their bounds themselves.  A ray nearly parallel to a cone's side gets one
+        // intersection that the reference does not check against the cone's ends (src/shapes/cone.rs:62-70): it
+        // may lie anywhere, so a cone is never passed over on account of its bounds.
+        bounded[(size_t)i] = finite && L.kind != RTAMD_MESH && L.kind != RTAMD_CONE;
+        has_box[(size_t)i] = finite;
         for (int k = 0; k < 3; k++) {
             // generous against rounding in this inverse and in the triangle test; no bound at all for odd data
             const double pad = finite ? 1e-6 * std::max({hi[k] - lo[k], std::fabs(lo[k]), std::fabs(hi[k]), 1e-30}) : INFINITY;
@@ -324,6 +325,32 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
     }
     if ((rc = upload(ctx, boxes.data(), boxes.size(), &d.mesh_box))) return rc;
+    // The pixel rectangle (x0, x1, y0, y1) that bounds what the camera sees of a world-space box; false when there is
+    // none (part of the box at or behind the camera, degenerate camera).
+    const rtamd_camera& C = s->camera;
+    const double* ci = C.inv;  // camera -> world; its inverse takes a world point to the camera's frame
+    const double cdet = ci[0] * (ci[5] * ci[10] - ci[6] * ci[9]) - ci[1] * (ci[4] * ci[10] - ci[6] * ci[8]) + ci[2] * (ci[4] * ci[9] - ci[5] * ci[8]);
+    double w2c[9] = {0};
+    const bool cam_ok = std::isfinite(cdet) && cdet != 0.0;
+    if (cam_ok) {
+        w2c[0] = (ci[5] * ci[10] - ci[6] * ci[9]) / cdet, w2c[1] = (ci[2] * ci[9] - ci[1] * ci[10]) / cdet, w2c[2] = (ci[1] * ci[6] - ci[2] * ci[5]) / cdet;
+        w2c[3] = (ci[6] * ci[8] - ci[4] * ci[10]) / cdet, w2c[4] = (ci[0] * ci[10] - ci[2] * ci[8]) / cdet, w2c[5] = (ci[2] * ci[4] - ci[0] * ci[6]) / cdet;
+        w2c[6] = (ci[4] * ci[9] - ci[5] * ci[8]) / cdet, w2c[7] = (ci[1] * ci[8] - ci[0] * ci[9]) / cdet, w2c[8] = (ci[0] * ci[5] - ci[1] * ci[4]) / cdet;
+    }
+    auto screen_rect = [&](const double* box, double r[4]) {
+        if (!cam_ok) return false;
+        r[0] = r[2] = INFINITY, r[1] = r[3] = -INFINITY;
+        for (int corner = 0; corner < 8; corner++) {
+            double pw[3], pc[3];
+            for (int k = 0; k < 3; k++) pw[k] = box[((corner >> k) & 1 ? 3 : 0) + k] - ci[4 * k + 3];
+            for (int k = 0; k < 3; k++) pc[k] = w2c[3 * k] * pw[0] + w2c[3 * k + 1] * pw[1] + w2c[3 * k + 2] * pw[2];
+            if (!(pc[2] < -1e-9)) return false;
+            const double px = (C.half_width - pc[0] / -pc[2]) / C.pixel_size, py = (C.half_height - pc[1] / -pc[2]) / C.pixel_size;
+            if (!std::isfinite(px) || !std::isfinite(py)) return false;
+            r[0] = std::min(r[0], px), r[1] = std::max(r[1], px), r[2] = std::min(r[2], py), r[3] = std::max(r[3], py);
+        }
+        return true;
+    };
     if ((rc = upload(ctx, s->chain, (size_t)s->n_chain * 12, &d.chain))) return rc;
     if ((rc = upload(ctx, s->tri_geom, (size_t)s->n_tris * 9, &d.tri_geom))) return rc;
     if ((rc = upload(ctx, s->tri_normals, (size_t)s->n_tris * 9, &d.tri_normals))) return rc;
@@ -413,7 +440,16 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         };
         // A bounds record costs about as much as two tests of an axis-aligned cube; it is worth having when
         // what it can save is several times that.  Rough costs in instructions per wave.
-        const double kBoundsCost = 45.0, kWorthIt = 10.0;
+        // A wave passes over the records only if all of its rays miss the box; the share of the frame outside the
+        // box's picture says how often that can happen for the rays that start at the camera.
+        const double kBoundsCost = 45.0, kWorthIt = 4.0;
+        auto outside = [&](const DVisit& B) {
+            double r[4];
+            if (!screen_rect(B.w2o, r)) return 0.0;
+            const double w = std::max(0.0, std::min(r[1], (double)C.hsize) - std::max(r[0], 0.0));
+            const double h = std::max(0.0, std::min(r[3], (double)C.vsize) - std::max(r[2], 0.0));
+            return 1.0 - w * h / ((double)C.hsize * (double)C.vsize);
+        };
         auto cost = [&](const DVisit& v) {
             const uint32_t kind = v.kind_flags & 0xffu;
             if (kind == DVISIT_BOUNDS) return 0.0;
@@ -440,11 +476,17 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 size_t inner_bounds = 0;
                 for (size_t b = a; b < std::min(j, a + 64); b += 8) {  // its inner groups
                     std::vector<DVisit> inner(in.begin() + (long)b, in.begin() + (long)std::min(j, b + 8));
-                    if (inner.size() > 1 && total(inner) >= kWorthIt * kBoundsCost) outer.push_back(bounds_record(inner)), inner_bounds++;
+                    if (inner.size() > 1) {
+                        const DVisit B = bounds_record(inner);
+                        if (total(inner) * outside(B) >= kWorthIt * kBoundsCost) outer.push_back(B), inner_bounds++;
+                    }
                     outer.insert(outer.end(), inner.begin(), inner.end());
                 }
                 const size_t leaves_in = outer.size() - inner_bounds;
-                if (leaves_in > 1 && total(outer) >= kWorthIt * kBoundsCost && !(inner_bounds == 1 && leaves_in <= 8)) out.push_back(bounds_record(outer));
+                if (leaves_in > 1 && !(inner_bounds == 1 && leaves_in <= 8)) {
+                    const DVisit B = bounds_record(outer);
+                    if (total(outer) * outside(B) >= kWorthIt * kBoundsCost) out.push_back(B);
+                }
                 out.insert(out.end(), outer.begin(), outer.end());
             }
             i = j;
@@ -474,69 +516,21 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     ctx->costly.clear();
     ctx->order_key = {{-1, -1, -1, -1, -1}};
     {
-        const rtamd_camera& C = s->camera;
-        const double* ci = C.inv;  // camera -> world; its inverse takes a world point to the camera's frame
-        const double cdet = ci[0] * (ci[5] * ci[10] - ci[6] * ci[9]) - ci[1] * (ci[4] * ci[10] - ci[6] * ci[8]) + ci[2] * (ci[4] * ci[9] - ci[5] * ci[8]);
-        double w2c[9] = {0};
-        bool usable = std::isfinite(cdet) && cdet != 0.0;
-        if (usable) {
-            w2c[0] = (ci[5] * ci[10] - ci[6] * ci[9]) / cdet, w2c[1] = (ci[2] * ci[9] - ci[1] * ci[10]) / cdet, w2c[2] = (ci[1] * ci[6] - ci[2] * ci[5]) / cdet;
-            w2c[3] = (ci[6] * ci[8] - ci[4] * ci[10]) / cdet, w2c[4] = (ci[0] * ci[10] - ci[2] * ci[8]) / cdet, w2c[5] = (ci[2] * ci[4] - ci[0] * ci[6]) / cdet;
-            w2c[6] = (ci[4] * ci[9] - ci[5] * ci[8]) / cdet, w2c[7] = (ci[1] * ci[8] - ci[0] * ci[9]) / cdet, w2c[8] = (ci[0] * ci[5] - ci[1] * ci[4]) / cdet;
-        }
+        bool usable = cam_ok;
         for (int i = 0; usable && i < s->n_leaves; i++) {
             const rtamd_leaf& L = s->leaves[i];
             const rtamd_material& M = s->materials[L.material];
             if (M.reflective == 0.0 || M.transparency == 0.0) continue;
-            // bounds in object space; an unbounded shape makes the whole screen costly, i.e. nothing is preferred
-            double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
-            if (L.kind == RTAMD_PLANE) {
-                usable = false;
-            } else if (L.kind == RTAMD_CYLINDER || L.kind == RTAMD_CONE) {
-                if (!std::isfinite(L.p0) || !std::isfinite(L.p1)) usable = false;
-                lo[1] = L.p0, hi[1] = L.p1;
-                if (L.kind == RTAMD_CONE) lo[0] = lo[2] = -std::max(std::fabs(L.p0), std::fabs(L.p1)), hi[0] = hi[2] = -lo[0];
-            } else if (L.kind == RTAMD_MESH) {
-                for (int k = 0; k < 3; k++) lo[k] = INFINITY, hi[k] = -INFINITY;
-                for (int t = L.tri_start; t < L.tri_start + L.tri_count; t++) {
-                    const double* g = s->tri_geom + (size_t)t * 9;
-                    for (int v = 0; v < 3; v++)
-                        for (int k = 0; k < 3; k++) {
-                            const double c = v == 0 ? g[k] : g[k] + g[3 * v + k];
-                            lo[k] = std::min(lo[k], c), hi[k] = std::max(hi[k], c);
-                        }
-                }
-            }
-            if (!usable) break;
-            const double* m = L.w2o;
-            const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
-            if (!std::isfinite(det) || det == 0.0) {
+            // a shape without bounds makes the whole screen costly, i.e. nothing is preferred
+            double r[4];
+            if (!has_box[(size_t)i] || !screen_rect(&boxes[(size_t)i * 6], r)) {
                 usable = false;
                 break;
             }
-            double o2w[9];
-            o2w[0] = (m[5] * m[10] - m[6] * m[9]) / det, o2w[1] = (m[2] * m[9] - m[1] * m[10]) / det, o2w[2] = (m[1] * m[6] - m[2] * m[5]) / det;
-            o2w[3] = (m[6] * m[8] - m[4] * m[10]) / det, o2w[4] = (m[0] * m[10] - m[2] * m[8]) / det, o2w[5] = (m[2] * m[4] - m[0] * m[6]) / det;
-            o2w[6] = (m[4] * m[9] - m[5] * m[8]) / det, o2w[7] = (m[1] * m[8] - m[0] * m[9]) / det, o2w[8] = (m[0] * m[5] - m[1] * m[4]) / det;
-            double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
-            for (int corner = 0; corner < 8 && usable; corner++) {
-                double po[3], pw[3], pc[3];
-                for (int k = 0; k < 3; k++) po[k] = ((corner >> k) & 1 ? hi[k] : lo[k]) - m[4 * k + 3];
-                for (int k = 0; k < 3; k++) pw[k] = o2w[3 * k] * po[0] + o2w[3 * k + 1] * po[1] + o2w[3 * k + 2] * po[2] - ci[4 * k + 3];
-                for (int k = 0; k < 3; k++) pc[k] = w2c[3 * k] * pw[0] + w2c[3 * k + 1] * pw[1] + w2c[3 * k + 2] * pw[2];
-                if (!(pc[2] < -1e-9)) {  // at or behind the camera: no rectangle bounds it
-                    usable = false;
-                    break;
-                }
-                const double px = (C.half_width - pc[0] / -pc[2]) / C.pixel_size, py = (C.half_height - pc[1] / -pc[2]) / C.pixel_size;
-                if (!std::isfinite(px) || !std::isfinite(py)) usable = false;
-                x0 = std::min(x0, px), x1 = std::max(x1, px), y0 = std::min(y0, py), y1 = std::max(y1, py);
-            }
-            if (!usable) break;
             auto pix = [](double v, int n) { return (int)std::min<double>(std::max<double>(v, -1.0), (double)n); };
-            std::array<int, 4> r{{pix(std::floor(x0) - 1, C.hsize), pix(std::ceil(x1) + 1, C.hsize), pix(std::floor(y0) - 1, C.vsize),
-                                  pix(std::ceil(y1) + 1, C.vsize)}};
-            if (r[1] >= 0 && r[0] < C.hsize && r[3] >= 0 && r[2] < C.vsize) ctx->costly.push_back(r);
+            std::array<int, 4> q{{pix(std::floor(r[0]) - 1, C.hsize), pix(std::ceil(r[1]) + 1, C.hsize), pix(std::floor(r[2]) - 1, C.vsize),
+                                  pix(std::ceil(r[3]) + 1, C.vsize)}};
+            if (q[1] >= 0 && q[0] < C.hsize && q[3] >= 0 && q[2] < C.vsize) ctx->costly.push_back(q);
         }
         if (!usable) ctx->costly.clear();
     }
