@@ -469,8 +469,11 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 out.push_back(in[i++]);
                 continue;
             }
+            // a run of triangle records, or a run of other bounded leaves: not mixed, the triangles of one object
+            // lie together and share little with the shapes around them
+            const bool tri_run = (in[i].kind_flags & 0xffu) == RTAMD_MESH;
             size_t j = i;
-            while (j < in.size() && is_mesh(in[j])) j++;
+            while (j < in.size() && is_mesh(in[j]) && ((in[j].kind_flags & 0xffu) == RTAMD_MESH) == tri_run) j++;
             for (size_t a = i; a < j; a += 64) {  // one outer group
                 std::vector<DVisit> outer;
                 size_t inner_bounds = 0;
