@@ -312,10 +312,8 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 add_point(q);
             }
         }
-        // Runs of triangles carry their bounds themselves.  A ray nearly parallel to a cone's side gets one
-        // intersection that the reference does not check against the cone's ends (src/shapes/cone.rs:62-70): it
-        // may lie anywhere, so a cone is never passed over on account of its bounds.
-        bounded[(size_t)i] = finite && L.kind != RTAMD_MESH && L.kind != RTAMD_CONE;
+        // Runs of triangles carry their bounds themselves.
+        bounded[(size_t)i] = finite && L.kind != RTAMD_MESH;
         has_box[(size_t)i] = finite;
         for (int k = 0; k < 3; k++) {
             // generous against rounding in this inverse and in the triangle test; no bound at all for odd data
@@ -413,6 +411,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     // Runs of records of bounded leaves get bounds records in front: one per 8 leaves, one per 64.  A bounds record
     // carries the union of the bounds below it and the number of records a wave may skip when none of
     // its rays meets them.  A record that closes an equality class is skipped only when it is that whole class.
+    std::vector<double> cone_dirs;
     auto with_bounds = [&](const std::vector<DVisit>& in) {
         // A record that closes a class may be skipped only when it is the whole class (the record before it
         // closed the previous one): the container pass then has nothing pending when it is passed over.
@@ -429,12 +428,35 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             DVisit B;
             std::memset(&B, 0, sizeof B);
             double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            // the kernel looks closer before it passes over a cone (rtamd_kernel.inc): the distinct orientations of
+            // the cones under this record
+            std::vector<std::array<double, 9>> dirs;
+            auto add_dir = [&](const double* m9) {
+                std::array<double, 9> a;
+                std::copy(m9, m9 + 9, a.begin());
+                if (std::find(dirs.begin(), dirs.end(), a) == dirs.end()) dirs.push_back(a);
+            };
             for (const DVisit& v : body) {
+                if ((v.kind_flags & 0xffu) == RTAMD_CONE) {
+                    const double* m = dl[(size_t)v.unit].w2o;
+                    const double m9[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+                    add_dir(m9);
+                } else if ((v.kind_flags & 0xffu) == DVISIT_BOUNDS && ((v.kind_flags >> 8) & DBOUNDS_HAS_CONE)) {
+                    int32_t sc[2];
+                    std::memcpy(sc, &v.p0, sizeof sc);
+                    for (int q = sc[0]; q < sc[0] + sc[1]; q++) add_dir(&cone_dirs[(size_t)q * 9]);
+                }
                 const double* b = (v.kind_flags & 0xffu) == DVISIT_BOUNDS ? v.w2o : &boxes[(size_t)v.unit * 6];
                 for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], b[k]), hi[k] = std::max(hi[k], b[3 + k]);
             }
             for (int k = 0; k < 3; k++) B.w2o[k] = lo[k], B.w2o[3 + k] = hi[k];
             B.kind_flags = DVISIT_BOUNDS;
+            if (!dirs.empty()) {
+                B.kind_flags |= DBOUNDS_HAS_CONE << 8;
+                const int32_t sc[2] = {(int32_t)(cone_dirs.size() / 9), (int32_t)dirs.size()};
+                std::memcpy(&B.p0, sc, sizeof sc);
+                for (const auto& a : dirs) cone_dirs.insert(cone_dirs.end(), a.begin(), a.end());
+            }
             B.unit = (int32_t)body.size();
             return B;
         };
@@ -510,6 +532,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     d.n_visits = (int)dv.size();
     d.n_visits_dfs = (int)dv_dfs.size();
     d.diag_thr = diag_thr;
+    if ((rc = upload(ctx, cone_dirs.data(), cone_dirs.size(), &d.cone_dirs))) return rc;
     dv_dfs.push_back(DVisit{});  // spare record: the loop over a run of cubes reads one record past the run
     if ((rc = upload(ctx, dv_dfs.data(), dv_dfs.size(), &d.visits_dfs))) return rc;
     if ((rc = upload(ctx, class_mat.data(), class_mat.size(), &d.class_material))) return rc;

@@ -53,7 +53,9 @@ struct alignas(16) DVisit {
     uint32_t vflags_class;  // 124  RTAMD_VISIT_* | eq_class << 8
 };
 
-#define DVISIT_BOUNDS 6u  // kind of a bounds record: w2o[0..5] = lo xyz, hi xyz (world space); unit = records to skip
+#define DBOUNDS_HAS_CONE 1u  // leaf flag of a bounds record: a cone is among the records it covers
+#define DVISIT_BOUNDS 6u  // kind of a bounds record: w2o[0..5] = lo xyz, hi xyz (world space); unit = records to skip;
+                          // with DBOUNDS_HAS_CONE the bytes of p0 hold int32 start, count of its list in DScene::cone_dirs
 
 struct DScene {
     rtamd_camera cam;
@@ -69,6 +71,7 @@ struct DScene {
     const DShade* shade;  // one per leaf
     const double* chain;
     const double* tri_geom;
+    const double* cone_dirs;  // 9 doubles each: the 3x3 part of the world -> object matrix of a cone (lists that bounds records point into)
     const double* mesh_box;  // per leaf 6 doubles: enlarged world-space bounds (lo xyz, hi xyz) of a MESH leaf's triangles
     const double* tri_normals;
     const rtamd_material* materials;
