@@ -232,6 +232,47 @@ def test_nested_csg_with_long_intersection_lists(rt, oracle, gpu_ctx, tmp_path):
         assert (np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2) <= 1).mean() >= 0.999
 
 
+def test_cone_hit_outside_its_bounds_survives_the_bounds_records(rt, oracle, gpu_ctx, tmp_path):
+    """src/shapes/cone.rs:62-70: a ray (nearly) parallel to a cone's side gets t = -c / 2b without the check
+    against the cone's ends, i.e. possibly far outside the truncated cone.  The library groups bounded leaves
+    under bounds records and passes over whole groups; it must not pass over a cone for such a ray."""
+    cones = "".join(f"""
+- add: cone
+  min: -1
+  max: 0
+  closed: true
+  transform:
+    - [scale, 0.2, 0.2, 0.2]
+    - [translate, {0.6 * i - 2.1}, 0, 0]
+  material:
+    color: [{0.2 + 0.1 * i}, 0.5, 0.3]
+    ambient: 0.4
+""" for i in range(8))
+    text = """
+- add: camera
+  width: 8
+  height: 8
+  field-of-view: 0.5
+  from: [0, 0, -40]
+  to: [0, 0, 0]
+  up: [0, 1, 0]
+- add: light
+  at: [-10, 10, -10]
+  intensity: [1, 1, 1]
+""" + cones
+    o = _world(rt, oracle, gpu_ctx, tmp_path, text)
+    r = 0.5 ** 0.5
+    rays = []
+    for x0 in np.linspace(-9.0, 5.0, 29):
+        for y0 in (-7.0, -3.0, 2.5):
+            for dx, dy in ((r, r), (r, -r), (-r, r), (r * (1 + 3e-6), r), (r, r * (1 - 6e-6))):
+                rays.append([x0, y0, 0.013, dx, dy, 0.0])
+    rays = np.array(rays)
+    ref = o.color_at(rays, 2)
+    assert (ref.sum(axis=1) > 0).sum() >= 20  # the case does occur: hits well outside every cone's bounds
+    _both(rt, gpu_ctx, o, rays, 2)
+
+
 @pytest.mark.parametrize("mode", ["strict", "fast"])
 def test_both_forms_of_the_triangle_test_give_the_same_bits(rt, gpu_ctx, mode):
     """A run of triangles is tested by a loop over its triangles (every lane its own ray) or, when few rays of a
