@@ -358,6 +358,17 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     std::vector<DVisit> dv((size_t)s->n_visits);
     std::vector<int32_t> class_mat((size_t)std::max(s->n_classes, 1), 0);
     double diag_thr = 0.0;
+    // the record of a CSG object: the bounds of all its leaves (no bounds at all when one of them has none, or is a
+    // cone: see the bounds records below)
+    auto csg_record = [&](DVisit& D, int root) {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool all = true;
+        for (int l = s->csg_roots[root].leaf_lo; l < s->csg_roots[root].leaf_hi; l++) {
+            all = all && has_box[(size_t)l] && s->leaves[l].kind != RTAMD_CONE;
+            for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], boxes[(size_t)l * 6 + k]), hi[k] = std::max(hi[k], boxes[(size_t)l * 6 + 3 + k]);
+        }
+        for (int k = 0; k < 3; k++) D.w2o[k] = all ? lo[k] : -INFINITY, D.w2o[3 + k] = all ? hi[k] : INFINITY;
+    };
     auto leaf_record = [&](DVisit& D, int leaf) {
         const DLeaf& L = dl[leaf];
         std::memcpy(D.w2o, L.w2o, sizeof D.w2o);
@@ -387,7 +398,10 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         class_mat[V.eq_class] = V.class_material;
         D.unit = V.unit;
         D.vflags_class = (V.flags & 0xffu) | ((uint32_t)V.eq_class << 8);
-        if (!(V.flags & RTAMD_VISIT_CSG)) leaf_record(D, V.unit);
+        if (V.flags & RTAMD_VISIT_CSG)
+            csg_record(D, V.unit);
+        else
+            leaf_record(D, V.unit);
     }
     // the same units once each, in depth-first order (what traversals without a container pass walk)
     std::vector<int> root_of((size_t)s->n_leaves, -1);
@@ -405,6 +419,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             if (i > 0 && root_of[i - 1] == root_of[i]) continue;
             D.unit = root_of[i];
             D.vflags_class = RTAMD_VISIT_FIRST | RTAMD_VISIT_CSG;
+            csg_record(D, D.unit);
         }
         dv_dfs.push_back(D);
     }
