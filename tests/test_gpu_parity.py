@@ -232,6 +232,62 @@ def test_nested_csg_with_long_intersection_lists(rt, oracle, gpu_ctx, tmp_path):
         assert (np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2) <= 1).mean() >= 0.999
 
 
+def test_containers_with_duplicate_objects_under_bounds_records(rt, oracle, gpu_ctx, tmp_path):
+    """Value-equal objects form one class of the n1/n2 container pass (src/shape.rs:23-27,
+    src/intersection.rs:88-112): two identical glass spheres toggle the same container entry.  Here such
+    duplicates sit in a row of small glass spheres that is long enough to get bounds records, so the pass
+    meets classes that span records while groups of records are being passed over."""
+    def sphere(x, y, r, ri, dup=1):
+        return "".join(f"""
+- add: sphere
+  transform:
+    - [scale, {r}, {r}, {r}]
+    - [translate, {x}, {y}, 0]
+  material:
+    color: [0.1, 0.2, 0.1]
+    diffuse: 0.3
+    reflective: 0.3
+    transparency: 0.8
+    refractive-index: {ri}
+""" for _ in range(dup))
+    text = """
+- add: camera
+  width: 120
+  height: 48
+  field-of-view: 0.9
+  from: [0, 0.4, -7]
+  to: [0, 0, 0]
+  up: [0, 1, 0]
+- add: light
+  at: [-6, 8, -10]
+  intensity: [1, 1, 1]
+- add: plane
+  transform:
+    - [translate, 0, -1, 0]
+  material:
+    pattern:
+      type: checkers
+      colors:
+        - [0.2, 0.2, 0.2]
+        - [0.8, 0.8, 0.8]
+"""
+    for i in range(10):
+        x = 0.62 * i - 2.8
+        text += sphere(x, -0.3, 0.3, 1.5, dup=2 if i % 3 == 0 else 1)  # exact duplicates: one class, two leaves
+        text += sphere(x, -0.3, 0.15, 1.1)                             # a smaller sphere inside each
+    text += sphere(0.0, 0.9, 0.5, 1.3) + sphere(0.0, 0.9, 0.5, 1.3)
+    sc = rt.Scene.from_yaml_str(text)
+    p = str(tmp_path / "dups.sg")
+    sc.save_sg(p)
+    w, h = 120, 48
+    ref, ref8, _ = oracle.OracleScene(p).render(w, h, threads=8)
+    gpu_ctx.upload(sc.flatten())
+    for mode, (m, tol) in _modes(rt).items():
+        rgb, u8 = gpu_ctx.render(w, h, m, want_u8=True)
+        assert np.abs(rgb - ref).max() <= tol, mode
+        assert (np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+
+
 def test_cone_hit_outside_its_bounds_survives_the_bounds_records(rt, oracle, gpu_ctx, tmp_path):
     """src/shapes/cone.rs:62-70: a ray (nearly) parallel to a cone's side gets t = -c / 2b without the check
     against the cone's ends, i.e. possibly far outside the truncated cone.  The library groups bounded leaves
