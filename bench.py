@@ -66,6 +66,10 @@ def main():
     ap.add_argument("--mode", default="fast", choices=["fast", "strict"])
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="frames rendering at once on a GPU (0: 1 on one GPU, 2 on several -- the tail of a frame, a few "
+                         "long chains of dependent rays, then overlaps the start of the next; kernel durations, and with "
+                         "them roofline.achieved, then include the time a kernel shares the GPU)")
     a = ap.parse_args()
 
     import torch
@@ -89,45 +93,54 @@ def main():
     mode = rt.MODE_FAST if a.mode == "fast" else rt.MODE_STRICT
     sg = os.path.join(ROOT, "tests", "golden", "scenes", a.scene + ".sg")
     scene = rt.Scene.from_sg(sg).set_resolution(a.width, a.height)
-    ctx = rt.Context(local_rank)
-    ctx.upload(scene.flatten())
+    in_flight = a.in_flight or (2 if world > 1 else 1)
+    flat = scene.flatten()
+    ctxs = [rt.Context(local_rank) for _ in range(in_flight)]  # a context owns the scratch of one render under way
+    for c in ctxs:
+        c.upload(flat)
+    ctx = ctxs[0]
     W, H, R = a.width, a.height, a.tile_rows
 
     if ctx.part_rows(R, rank, world) != len(rows_mod.part_row_indices(H, R, rank, world)):
         raise SystemExit("row partition of the library and of rows.py disagree")
     fg = rows_mod.FrameGather(W, H, R, rank, world, dev)
-    frame = fg.frame
-    stream = torch.cuda.current_stream().cuda_stream
+    streams = [torch.cuda.current_stream()] if in_flight == 1 else [torch.cuda.Stream() for _ in range(in_flight)]
 
-    def step():  # frame k's rows travel to rank 0 while frame k + 1 renders (rows.FrameGather.exchange)
-        ctx.render_rows(R, rank, world, mode, d_rgb=fg.local.data_ptr(), stream=stream)
-        fg.exchange()
+    def step(k, events=None):  # frame k's rows travel to rank 0 while the next frames render (rows.FrameGather)
+        j = k % in_flight
+        with torch.cuda.stream(streams[j]):
+            buf = fg.begin()
+            if events:
+                events[0].record()  # events bracket the render kernel itself, on the stream it is launched on
+            ctxs[j].render_rows(R, rank, world, mode, d_rgb=buf.data_ptr(), stream=streams[j].cuda_stream)
+            if events:
+                events[1].record()
+            fg.submit()
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for k in range(max(a.warmup, in_flight if a.warmup else 0)):
+        step(k)
     fg.finish()
     sync()
-    ctx.reset_stats()
+    for c in ctxs:
+        c.reset_stats()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     sync()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        ev[k][0].record()  # events bracket the render kernel itself, on the stream it is launched on
-        ctx.render_rows(R, rank, world, mode, d_rgb=fg.local.data_ptr(), stream=stream)
-        ev[k][1].record()
-        fg.exchange()
-    fg.finish()  # the last frame is complete on rank 0 inside the timed region
+        step(k, ev[k])
+    frame = fg.finish()  # every frame is complete on rank 0 inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
-    st = ctx.stats()
+    sts = [c.stats() for c in ctxs]
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
-    counts = torch.tensor([st.primary_rays + st.shadow_rays + st.reflect_rays + st.refract_rays, st.shade_points,
-                           st.light_samples, st.container_passes], dtype=torch.float64, device=dev)
+    counts = torch.tensor([sum(st.primary_rays + st.shadow_rays + st.reflect_rays + st.refract_rays for st in sts),
+                           sum(st.shade_points for st in sts), sum(st.light_samples for st in sts),
+                           sum(st.container_passes for st in sts)], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(counts)
@@ -151,7 +164,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.scene} scene graph at {W}x{H}, recursion budget 4, {a.mode} arithmetic",
-                       "rays_per_frame": rays, "pixels": W * H, "row_tiles": f"cyclic, {R} rows", "parallelism": f"rows{world}"},
+                       "rays_per_frame": rays, "pixels": W * H, "row_tiles": f"cyclic, {R} rows", "parallelism": f"rows{world}",
+                       "frames_in_flight": in_flight},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": achieved / (FP64_VALU_PEAK_TFLOPS * world), "traffic": traffic,
                          "kernel_ms": kernel_ms, "flops_per_ray": fpr, "algorithmic_flops_per_frame": flops,

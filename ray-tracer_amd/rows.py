@@ -22,13 +22,15 @@ def part_row_indices(vsize, tile_rows, part, n_parts):
 
 
 class FrameGather:
-    """Buffers and the exchange step of one rank.
+    """Buffers and the exchange step of one rank, for two frames in flight.
 
-    ``local``  (max_rows, hsize, 3) float64: this rank's rows of the frame being rendered, compact, in
-               increasing row order (ranks with fewer rows leave the tail unused so that every rank sends
-               the same size).  There are two such buffers: ``exchange`` starts the gather of the one just
-               filled and hands out the other, so the next frame renders while this one travels;
-    ``frame``  (vsize, hsize, 3) float64 on rank 0, else None.
+    A frame slot holds ``local`` (max_rows, hsize, 3) float64 -- this rank's rows, compact, in increasing row
+    order (ranks with fewer rows leave the tail unused so that every rank sends the same size) -- and on rank 0
+    the gathered parts and the assembled ``frame`` (vsize, hsize, 3).  ``begin`` hands out the next slot's
+    ``local`` after completing the frame that slot carried before, ``submit`` starts that slot's gather without
+    waiting for it.  So a frame's rows travel while the next frame renders, and -- when the caller alternates two
+    streams -- two renders may overlap as well: nothing a slot touches is shared with the other slot.
+    ``gather`` is the plain blocking form.
     """
 
     def __init__(self, hsize, vsize, tile_rows, rank, world, device):
@@ -36,49 +38,53 @@ class FrameGather:
         self.rows = [part_row_indices(vsize, tile_rows, p, world) for p in range(world)]
         max_rows = max(len(r) for r in self.rows)
         self.n_rows = len(self.rows[rank])
-        self.frame = torch.empty((vsize, hsize, 3), dtype=torch.float64, device=device) if rank == 0 else None
-        self._pending = None
+        self._frames = [torch.empty((vsize, hsize, 3), dtype=torch.float64, device=device) if rank == 0 else None for _ in range(2)]
+        self._pending = [None, None]
+        self._cur = 0      # the slot begin() handed out last
+        self._newest = 0   # the slot submitted last
         if world == 1:
-            self.local = self.frame  # a single rank renders straight into the frame
-            return
-        self._locals = [torch.empty((max_rows, hsize, 3), dtype=torch.float64, device=device) for _ in range(2)]
-        self._cur = 0
+            self._locals = self._frames  # a single rank renders straight into the frame
+        else:
+            self._locals = [torch.empty((max_rows, hsize, 3), dtype=torch.float64, device=device) for _ in range(2)]
+            self._gathered = [[torch.empty_like(self._locals[0]) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+            self._dst = [torch.from_numpy(r).to(device) for r in self.rows] if rank == 0 else None
         self.local = self._locals[0]
-        self._gathered = [torch.empty_like(self.local) for _ in range(world)] if rank == 0 else None
-        self._dst = [torch.from_numpy(r).to(device) for r in self.rows] if rank == 0 else None
+        self.frame = self._frames[0]
 
-    def _place(self):
-        """Rank 0: the gathered parts go to their rows of the frame."""
+    def _complete(self, slot):
+        """Waits for the gather of ``slot`` (if one is under way) and, on rank 0, puts the parts into the frame."""
+        if self._pending[slot] is None:
+            return
+        self._pending[slot].wait()
+        self._pending[slot] = None
         if self.rank == 0:
             for p in range(self.world):
-                self.frame.index_copy_(0, self._dst[p], self._gathered[p][: self._dst[p].numel()])
+                self._frames[slot].index_copy_(0, self._dst[p], self._gathered[slot][p][: self._dst[p].numel()])
 
-    def gather(self):
-        """Collective: every rank calls it after filling ``local``; rank 0 ends with the whole frame."""
-        if self.world == 1:
-            return self.frame
-        self.finish()
-        dist.gather(self.local, self._gathered, dst=0)
-        self._place()
-        return self.frame
-
-    def exchange(self):
-        """Collective, pipelined form of ``gather``: completes the frame submitted by the previous call
-        (rank 0's ``frame`` then holds that frame), starts the gather of the frame just rendered into
-        ``local`` without waiting for it, and makes ``local`` the other buffer.  ``finish`` completes the
-        last frame.  With a device backend everything is ordered on streams: the caller may launch the next
-        render right away, and it overlaps this frame's transfer."""
-        if self.world == 1:
-            return
-        self.finish()
-        self._pending = dist.gather(self.local, self._gathered, dst=0, async_op=True)
+    def begin(self):
+        """The buffer to render the next frame into (``local``); completes the frame its slot carried before."""
         self._cur ^= 1
+        if self.world > 1:
+            self._complete(self._cur)
         self.local = self._locals[self._cur]
+        return self.local
+
+    def submit(self):
+        """Collective: starts the gather of the frame rendered into ``local``; returns at once.  With a device
+        backend the transfer is ordered after the work queued so far on the current stream."""
+        self._newest = self._cur
+        if self.world > 1:
+            self._pending[self._cur] = dist.gather(self.local, self._gathered[self._cur], dst=0, async_op=True)
 
     def finish(self):
-        """Completes the frame whose gather ``exchange`` started (no-op when there is none)."""
-        if self._pending is not None:
-            self._pending.wait()
-            self._pending = None
-            self._place()
+        """Completes every frame under way, oldest first; rank 0 gets the newest frame (``frame``)."""
+        if self.world > 1:
+            self._complete(self._newest ^ 1)
+            self._complete(self._newest)
+        self.frame = self._frames[self._newest]
         return self.frame
+
+    def gather(self):
+        """Collective, blocking: every rank calls it after filling ``local``; rank 0 ends with the whole frame."""
+        self.submit()
+        return self.finish()

@@ -32,18 +32,20 @@ def main():
         fg.local[: len(mine)] = torch.from_numpy(rgb.reshape(len(mine), w, 3))
     for _ in range(2):  # the exchange is repeatable
         frame = fg.gather()
-    # the pipelined form bench.py uses: frame k travels while frame k + 1 is produced (here: frame + k)
+    # the pipelined form bench.py uses: two frames under way (here: frame + k)
     mine_rows = fg.local[: len(mine)].clone()
     first = frame.clone() if rank == 0 else None
-    for k in range(1, 4):
-        fg.local.fill_(float("nan"))
-        fg.local[: len(mine)] = mine_rows + k
-        fg.exchange()
-        if rank == 0 and k > 1:  # the frame submitted one call earlier is complete now
-            assert torch.equal(fg.frame, first + (k - 1)), k
+    for k in range(1, 6):
+        buf = fg.begin()  # completes frame k - 2, whose slot this is
+        if rank == 0 and k > 2:
+            assert torch.equal(fg._frames[fg._cur], first + (k - 2)), k
+        buf.fill_(float("nan"))
+        buf[: len(mine)] = mine_rows + k
+        fg.submit()
     frame = fg.finish()
     if rank == 0:
-        assert torch.equal(frame, first + 3)
+        assert torch.equal(frame, first + 5)
+        assert torch.equal(fg._frames[fg._newest ^ 1], first + 4)
         frame = first
     dist.barrier()
     if rank == 0:
