@@ -19,6 +19,7 @@
 #ifndef RTAMD_H
 #define RTAMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -192,8 +193,15 @@ int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows);
  * (src/tuple.rs:226-237), may be NULL. Asynchronous on `stream` (a hipStream_t, NULL = default). */
 int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream);
 
-/* Camera::render for the whole frame into host memory (either pointer may be NULL). Blocking. */
+/* Camera::render for the whole frame into host memory (either pointer may be NULL). Blocking.
+ * The device-side frame is kept by the context between calls; the copy back runs at the rate of the
+ * PCIe link when the destination came from rtamd_host_alloc, and through the driver's staging otherwise. */
 int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8);
+
+/* Page-locked host memory for the frame: what Canvas::new's Vec<Color> (src/tuple.rs:315-321) becomes when
+ * the canvas is to receive a GPU render. NULL when the allocation fails. */
+void* rtamd_host_alloc(size_t bytes);
+void rtamd_host_free(void* p);
 
 /* World::color_at(ray, remaining) (src/scene.rs:53-63) for n caller-supplied rays:
  * h_rays = n x 6 doubles (origin xyz, direction xyz), h_rgb = n x 3 doubles. Blocking. */

@@ -63,7 +63,8 @@ class Rows(C.Structure):
 
 # every symbol include/rtamd.h declares
 GPU_SYMBOLS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error", "rtamd_scene_upload", "rtamd_part_rows",
-               "rtamd_render_rows", "rtamd_render", "rtamd_color_at", "rtamd_get_stats", "rtamd_reset_stats"]
+               "rtamd_render_rows", "rtamd_render", "rtamd_host_alloc", "rtamd_host_free", "rtamd_color_at", "rtamd_get_stats",
+               "rtamd_reset_stats"]
 
 _gpu.rtamd_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
 _gpu.rtamd_ctx_create.restype = C.c_int
@@ -79,6 +80,10 @@ _gpu.rtamd_render_rows.argtypes = [C.c_void_p, C.POINTER(Rows), C.c_int, C.c_voi
 _gpu.rtamd_render_rows.restype = C.c_int
 _gpu.rtamd_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 _gpu.rtamd_render.restype = C.c_int
+_gpu.rtamd_host_alloc.argtypes = [C.c_size_t]
+_gpu.rtamd_host_alloc.restype = C.c_void_p
+_gpu.rtamd_host_free.argtypes = [C.c_void_p]
+_gpu.rtamd_host_free.restype = None
 _gpu.rtamd_color_at.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
 _gpu.rtamd_color_at.restype = C.c_int
 _gpu.rtamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -243,12 +248,14 @@ class Context:
         self._chk(_gpu.rtamd_render_rows(self._h, C.byref(r), mode, C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None),
                                          C.c_void_p(stream or None)))
 
-    def render(self, hsize, vsize, mode=MODE_FAST, want_u8=False):
-        """Whole frame into host arrays; (hsize, vsize) must be the resolution of the uploaded scene."""
+    def render(self, hsize, vsize, mode=MODE_FAST, want_u8=False, pinned=False):
+        """Whole frame into host arrays; (hsize, vsize) must be the resolution of the uploaded scene.
+        ``pinned``: the arrays live in page-locked memory from rtamd_host_alloc (freed with the arrays)."""
         if getattr(self, "_size", None) is not None and self._size != (hsize, vsize):
             raise RtamdError(f"the uploaded scene is {self._size[0]}x{self._size[1]}, not {hsize}x{vsize}")
-        rgb = np.empty((vsize, hsize, 3), dtype=np.float64)
-        u8 = np.empty((vsize, hsize, 3), dtype=np.uint8) if want_u8 else None
+        new = host_empty if pinned else np.empty
+        rgb = new((vsize, hsize, 3), dtype=np.float64)
+        u8 = new((vsize, hsize, 3), dtype=np.uint8) if want_u8 else None
         self._chk(_gpu.rtamd_render(self._h, mode, rgb.ctypes.data, u8.ctypes.data if want_u8 else None))
         return (rgb, u8) if want_u8 else rgb
 
@@ -273,6 +280,31 @@ class Context:
 
     def __del__(self):
         self.close()
+
+
+class _Pinned:
+    """Frees one rtamd_host_alloc block when the last array made from it is gone."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        if self.ptr and _gpu is not None:
+            _gpu.rtamd_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (rtamd_host_alloc)."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(1, count * dtype.itemsize)
+    ptr = _gpu.rtamd_host_alloc(nbytes)
+    if not ptr:
+        raise RtamdError(f"rtamd_host_alloc({nbytes}) failed")
+    buf = (C.c_char * nbytes).from_address(ptr)
+    buf._owner = _Pinned(ptr)  # the buffer is the array's base: the block lives as long as any view of it
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 def quantize(rgb):

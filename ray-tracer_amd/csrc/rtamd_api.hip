@@ -46,6 +46,10 @@ struct rtamd_ctx {
     size_t order_cap = 0;
     std::array<int64_t, 5> order_key{{-1, -1, -1, -1, -1}};
     bool order_used = false;
+    // device-side frame of rtamd_render (host destination), kept between calls
+    double* d_out = nullptr;
+    uint8_t* d_out8 = nullptr;
+    size_t out_cap = 0, out8_cap = 0;
 };
 
 static std::string g_create_err;
@@ -131,6 +135,8 @@ void rtamd_ctx_destroy(rtamd_ctx* ctx) {
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->d_out8) (void)hipFree(ctx->d_out8);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -707,10 +713,22 @@ int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
     if (!ctx->have_scene) return fail(ctx, RTAMD_E_NO_SCENE, "no scene uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     size_t npx = (size_t)ctx->ds.cam.hsize * ctx->ds.cam.vsize;
-    double* d_rgb = nullptr;
-    uint8_t* d_u8 = nullptr;
-    if (h_rgb) HIPCHK(ctx, hipMalloc(&d_rgb, npx * 3 * sizeof(double)));
-    if (h_rgb8) HIPCHK(ctx, hipMalloc(&d_u8, npx * 3));
+    if (h_rgb && ctx->out_cap < npx * 3 * sizeof(double)) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        if (ctx->d_out) HIPCHK(ctx, hipFree(ctx->d_out));
+        ctx->d_out = nullptr, ctx->out_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_out, npx * 3 * sizeof(double)));
+        ctx->out_cap = npx * 3 * sizeof(double);
+    }
+    if (h_rgb8 && ctx->out8_cap < npx * 3) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        if (ctx->d_out8) HIPCHK(ctx, hipFree(ctx->d_out8));
+        ctx->d_out8 = nullptr, ctx->out8_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_out8, npx * 3));
+        ctx->out8_cap = npx * 3;
+    }
+    double* d_rgb = h_rgb ? ctx->d_out : nullptr;
+    uint8_t* d_u8 = h_rgb8 ? ctx->d_out8 : nullptr;
     rtamd_rows all{ctx->ds.cam.vsize, 0, 1};
     int rc = rtamd_render_rows(ctx, &all, mode, d_rgb, d_u8, nullptr);
     if (rc == RTAMD_OK) {
@@ -719,14 +737,21 @@ int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
         if (e == hipSuccess && h_rgb8) e = hipMemcpy(h_rgb8, d_u8, npx * 3, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, RTAMD_E_HIP, std::string("render: ") + hipGetErrorString(e));
     }
-    if (d_rgb) (void)hipFree(d_rgb);
-    if (d_u8) (void)hipFree(d_u8);
     if (rc == RTAMD_OK) {
         rtamd_stats st;
         if (ctx->has_csg && rtamd_get_stats(ctx, &st) == RTAMD_OK && st.csg_overflows)
             rc = fail(ctx, RTAMD_E_OVERFLOW, "a per-lane CSG intersection list overflowed (RTAMD_CSG_LIST_CAP)");
     }
     return rc;
+}
+
+void* rtamd_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void rtamd_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int rtamd_color_at(rtamd_ctx* ctx, int mode, const double* h_rays, int64_t n, int remaining, double* h_rgb) {

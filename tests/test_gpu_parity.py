@@ -384,6 +384,21 @@ def test_render_is_deterministic_and_contexts_are_independent(rt, gpu_ctx):
     assert np.array_equal(a, b)
 
 
+def test_render_into_page_locked_memory(rt, gpu_ctx):
+    """rtamd_host_alloc / rtamd_host_free: the same frame, whichever kind of host memory receives it; the
+    context keeps its device-side frame between calls and across a change of resolution."""
+    for w, h in ((96, 54), (160, 90), (64, 32)):
+        _upload(rt, gpu_ctx, "cover", w, h)
+        a, a8 = gpu_ctx.render(w, h, rt.MODE_FAST, want_u8=True)
+        b, b8 = gpu_ctx.render(w, h, rt.MODE_FAST, want_u8=True, pinned=True)
+        assert np.array_equal(a, b) and np.array_equal(a8, b8)
+        assert np.array_equal(gpu_ctx.render(w, h, rt.MODE_FAST, pinned=True), a)  # without the 8-bit frame
+    row = b[0].copy()
+    view = b[0]
+    del b
+    assert np.array_equal(view, row)  # a view keeps the block alive
+
+
 def test_host_api_render_goes_through_the_gpu(rt):
     """Scene.render = Camera::render of the host library: flatten, upload, rtamd_render."""
     sc = rt.Scene.from_sg(sg_path("default_world"))
