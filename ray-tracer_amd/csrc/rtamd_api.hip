@@ -549,8 +549,23 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                            ((dv_dfs[i + 1].kind_flags ^ D.kind_flags) & (RTAMD_LEAF_SHADOW << 8)) == 0;
         D.run = joins ? dv_dfs[i + 1].run + 1 : 1;
     }
+    // the same in the class-major list, for cubes that are a class of their own (marked before the bounds records go in)
+    for (size_t i = 0; i < dv.size(); i++) {
+        const uint32_t want = (uint32_t)RTAMD_CUBE | (DLEAF_DIAG << 8), mask = 0xffu | (DLEAF_DIAG << 8);
+        DVisit& D = dv[i];
+        const bool own_class = (D.vflags_class & RTAMD_VISIT_CLASS_END) && (i == 0 || (dv[i - 1].vflags_class & RTAMD_VISIT_CLASS_END));
+        D.run = !(D.vflags_class & RTAMD_VISIT_CSG) && (D.kind_flags & mask) == want && own_class ? 1 : 0;
+    }
     dv = with_bounds(dv);
-    d.n_visits = (int)dv.size();
+    for (size_t i = dv.size(); i-- > 0;) {
+        DVisit& D = dv[i];
+        if ((D.kind_flags & 0xffu) == DVISIT_BOUNDS || D.run == 0) continue;
+        const bool joins = i + 1 < dv.size() && (dv[i + 1].kind_flags & 0xffu) != DVISIT_BOUNDS && dv[i + 1].run > 0 &&
+                           ((dv[i + 1].kind_flags ^ D.kind_flags) & (RTAMD_LEAF_SHADOW << 8)) == 0;
+        D.run = joins ? dv[i + 1].run + 1 : 1;
+    }
+    dv.push_back(DVisit{});  // spare record, as in the depth-first list
+    d.n_visits = (int)dv.size() - 1;
     d.n_visits_dfs = (int)dv_dfs.size();
     d.diag_thr = diag_thr;
     if ((rc = upload(ctx, cone_dirs.data(), cone_dirs.size(), &d.cone_dirs))) return rc;
