@@ -199,6 +199,12 @@ def cpu_baseline(a, sg, frame, rt):
     t0 = time.perf_counter()
     rgb, u8, st = o.render_pixels(pix, W, H, faithful=True)
     dt = time.perf_counter() - t0
+    # the same oracle with cached inverses and children evaluated once per shade point, on the same sample: how much
+    # of the speed-up is owed to the reference's redundant work rather than to the GPU
+    sub = pix
+    t0 = time.perf_counter()
+    _, _, st_c = o.render_pixels(sub, W, H, faithful=False)
+    dt_c = time.perf_counter() - t0
     import torch
     gpu = frame.reshape(-1, 3)[torch.from_numpy(pix).to(frame.device)].cpu().numpy()
     g8 = rt.quantize(gpu)
@@ -206,7 +212,9 @@ def cpu_baseline(a, sg, frame, rt):
     base = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"{pix.size} pixels (every {stride}-th of the {W}x{H} frame), oracle in faithful mode, 1 thread, {dt:.1f} s",
             "rays_reference_equivalent_per_frame": st["rays"] / pix.size * npx,
-            "est_frame_seconds": dt / pix.size * npx, "host_cpus": os.cpu_count()}
+            "est_frame_seconds": dt / pix.size * npx, "host_cpus": os.cpu_count(),
+            "cached_mode": {"value": st_c["rays"] / dt_c / 1e6, "unit": "Mrays/s", "est_frame_seconds": dt_c / sub.size * npx,
+                            "sample": f"{sub.size} pixels, {dt_c:.1f} s"}}
     parity = {"pixels_checked": int(pix.size), "max_abs_f64": float(np.abs(gpu - rgb).max()),
               "u8_within_1_lsb": float((d8 <= 1).mean()), "u8_equal": float((d8 == 0).mean())}
     return base, parity
