@@ -654,7 +654,16 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     w.total_lanes = ctx->total_lanes;
     int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->variant], (w.n_pixels + 255) / 256);
     blocks = std::max(blocks, 1);
-    w.n_groups = (w.n_pixels + 63) / 64;
+    // Camera rays: blocks of 8 x 8 pixels when the row tiles are whole multiples of 8 rows (no block then straddles
+    // two tiles, which lie far apart in the frame); strips of 64 pixels otherwise and for caller-supplied rays.
+    w.gcols = 0, w.n_rows = 0;
+    if (!w.custom_rays && w.tile_rows % 8 == 0 && w.hsize >= 8) {
+        w.n_rows = (int32_t)(w.n_pixels / w.hsize);
+        w.gcols = (w.hsize + 7) / 8;
+        w.n_groups = (int64_t)w.gcols * ((w.n_rows + 7) / 8);
+    } else {
+        w.n_groups = (w.n_pixels + 63) / 64;
+    }
     w.group_stride = coprime_stride(w.n_groups);
     w.order = nullptr;
     w.mesh_few = 16;
@@ -669,13 +678,20 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
             first.reserve((size_t)w.n_groups), rest.reserve((size_t)w.n_groups);
             for (int64_t j = 0; j < w.n_groups; j++) {
                 const int64_t grp = (j * w.group_stride) % w.n_groups;
-                const int64_t p0 = grp * 64, p1 = std::min<int64_t>(p0 + 63, w.n_pixels - 1);
                 bool hot = false;
-                for (int64_t lrow = p0 / w.hsize; lrow <= p1 / w.hsize && !hot; lrow++) {
+                auto touches = [&](int64_t lrow, int64_t xa, int64_t xb) {  // pixels xa..xb of row lrow of this part
                     const int64_t tile = lrow / w.tile_rows;
                     const int64_t py = (tile * w.n_parts + w.part) * w.tile_rows + (lrow - tile * w.tile_rows);
-                    const int64_t xa = std::max<int64_t>(p0 - lrow * w.hsize, 0), xb = std::min<int64_t>(p1 - lrow * w.hsize, w.hsize - 1);
                     for (const auto& r : ctx->costly) hot |= py >= r[2] && py <= r[3] && xb >= r[0] && xa <= r[1];
+                };
+                if (w.gcols) {
+                    const int64_t gy = grp / w.gcols, gx = grp - gy * w.gcols;
+                    for (int64_t lrow = gy * 8; lrow < std::min<int64_t>(gy * 8 + 8, w.n_rows) && !hot; lrow++)
+                        touches(lrow, gx * 8, std::min<int64_t>(gx * 8 + 7, w.hsize - 1));
+                } else {
+                    const int64_t p0 = grp * 64, p1 = std::min<int64_t>(p0 + 63, w.n_pixels - 1);
+                    for (int64_t lrow = p0 / w.hsize; lrow <= p1 / w.hsize && !hot; lrow++)
+                        touches(lrow, std::max<int64_t>(p0 - lrow * w.hsize, 0), std::min<int64_t>(p1 - lrow * w.hsize, w.hsize - 1));
                 }
                 (hot ? first : rest).push_back((int32_t)grp);
             }

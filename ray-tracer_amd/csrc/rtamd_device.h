@@ -108,7 +108,9 @@ struct DWork {
     int32_t tile_rows, part, n_parts;
     int32_t remaining;          // recursion budget of the primary rays
     int64_t n_pixels;           // pixels of this part (or number of custom rays)
-    int64_t n_groups;           // ceil(n_pixels / 64): the unit of the work queue
+    int64_t n_groups;           // the units of the work queue: groups of 64 pixels
+    int32_t gcols, n_rows;      // gcols != 0: a group is a block of 8 x 8 pixels, gcols blocks side by side, over the part's
+                                // n_rows rows; gcols == 0: a group is 64 consecutive pixels (ceil(n_pixels / 64) groups)
     int64_t group_stride;       // coprime to n_groups: queue position g stands for pixel group (g * stride) % n_groups
     const double* custom_rays;  // NULL: camera rays; else n_pixels x 6
     const int32_t* order;       // NULL: groups in strided order; else queue position -> group of 64 pixels
