@@ -659,7 +659,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     w.gcols = 0, w.n_rows = 0;
     if (!w.custom_rays && w.tile_rows % 8 == 0 && w.hsize >= 8) {
         w.n_rows = (int32_t)(w.n_pixels / w.hsize);
-        w.gcols = (w.hsize + 7) / 8;
+        w.gcols = (w.hsize + RTAMD_BLOCK_W - 1) / RTAMD_BLOCK_W;
         w.n_groups = (int64_t)w.gcols * ((w.n_rows + 7) / 8);
     } else {
         w.n_groups = (w.n_pixels + 63) / 64;
@@ -687,7 +687,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
                 if (w.gcols) {
                     const int64_t gy = grp / w.gcols, gx = grp - gy * w.gcols;
                     for (int64_t lrow = gy * 8; lrow < std::min<int64_t>(gy * 8 + 8, w.n_rows) && !hot; lrow++)
-                        touches(lrow, gx * 8, std::min<int64_t>(gx * 8 + 7, w.hsize - 1));
+                        touches(lrow, gx * RTAMD_BLOCK_W, std::min<int64_t>(gx * RTAMD_BLOCK_W + RTAMD_BLOCK_W - 1, w.hsize - 1));
                 } else {
                     const int64_t p0 = grp * 64, p1 = std::min<int64_t>(p0 + 63, w.n_pixels - 1);
                     for (int64_t lrow = p0 / w.hsize; lrow <= p1 / w.hsize && !hot; lrow++)

@@ -96,6 +96,7 @@ enum {
 };
 
 #define RTAMD_CSG_LIST_SMALL 12  // list length of the kernel variant for small CSG objects
+#define RTAMD_BLOCK_W 8          // width in pixels of a work-queue block (8 rows high)
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
 #define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
 #define RTAMD_FRAME_F64 22   // doubles per saved shade-point frame
