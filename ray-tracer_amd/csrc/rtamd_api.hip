@@ -485,7 +485,8 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         // what it can save is several times that.  Rough costs in instructions per wave.
         // A wave passes over the records only if all of its rays miss the box; the share of the frame outside the
         // box's picture says how often that can happen for the rays that start at the camera.
-        const double kBoundsCost = 45.0, kWorthIt = 4.0;
+        const double kBoundsCost = 45.0;
+        const double kWorthIt = getenv("RTAMD_BOUNDS_WORTH") ? atof(getenv("RTAMD_BOUNDS_WORTH")) : 2.0;  // (diagnostic override)
         auto outside = [&](const DVisit& B) {
             double r[4];
             if (!screen_rect(B.w2o, r)) return 0.0;
@@ -666,7 +667,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     }
     w.group_stride = coprime_stride(w.n_groups);
     w.order = nullptr;
-    w.mesh_few = 16;
+    w.mesh_few = 32;
     if (const char* e = getenv("RTAMD_MESH_FEW")) w.mesh_few = atoi(e);  // diagnostic: 0 = always the loop, 64 = never
     if (!w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
         // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
