@@ -667,6 +667,11 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     }
     w.group_stride = coprime_stride(w.n_groups);
     w.order = nullptr;
+    // A wave finishes its group of pixels before it asks for the next one: its lanes then go through the phases of
+    // a pixel more or less together (fewer phases to execute per iteration, rays of one kind side by side), which
+    // is worth more than the lanes that idle towards the end of a group.
+    w.refill_min = 64;
+    if (const char* e = getenv("RTAMD_REFILL_MIN")) w.refill_min = atoi(e);  // diagnostic
     w.mesh_few = 32;
     if (const char* e = getenv("RTAMD_MESH_FEW")) w.mesh_few = atoi(e);  // diagnostic: 0 = always the loop, 64 = never
     if (!w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {

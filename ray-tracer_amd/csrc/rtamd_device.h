@@ -115,6 +115,7 @@ struct DWork {
     int64_t group_stride;       // coprime to n_groups: queue position g stands for pixel group (g * stride) % n_groups
     const double* custom_rays;  // NULL: camera rays; else n_pixels x 6
     const int32_t* order;       // NULL: groups in strided order; else queue position -> group of 64 pixels
+    int32_t refill_min;         // a wave asks for its next group of pixels when at least this many of its lanes are idle
     int32_t mesh_few;           // a run of triangles that at most this many rays of a wave come near is tested one triangle per lane
     double* out_rgb;            // may be NULL
     uint8_t* out_rgb8;          // may be NULL
