@@ -655,13 +655,13 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     w.total_lanes = ctx->total_lanes;
     int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->variant], (w.n_pixels + 255) / 256);
     blocks = std::max(blocks, 1);
-    // Camera rays: blocks of 8 x 8 pixels when the row tiles are whole multiples of 8 rows (no block then straddles
+    // Camera rays: blocks of RTAMD_BLOCK_W x RTAMD_BLOCK_H pixels when the row tiles are whole multiples of the block height (no block then straddles
     // two tiles, which lie far apart in the frame); strips of 64 pixels otherwise and for caller-supplied rays.
     w.gcols = 0, w.n_rows = 0;
-    if (!w.custom_rays && w.tile_rows % 8 == 0 && w.hsize >= 8) {
+    if (!w.custom_rays && w.tile_rows % RTAMD_BLOCK_H == 0 && w.hsize >= RTAMD_BLOCK_W) {
         w.n_rows = (int32_t)(w.n_pixels / w.hsize);
         w.gcols = (w.hsize + RTAMD_BLOCK_W - 1) / RTAMD_BLOCK_W;
-        w.n_groups = (int64_t)w.gcols * ((w.n_rows + 7) / 8);
+        w.n_groups = (int64_t)w.gcols * ((w.n_rows + RTAMD_BLOCK_H - 1) / RTAMD_BLOCK_H);
     } else {
         w.n_groups = (w.n_pixels + 63) / 64;
     }
@@ -692,7 +692,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
                 };
                 if (w.gcols) {
                     const int64_t gy = grp / w.gcols, gx = grp - gy * w.gcols;
-                    for (int64_t lrow = gy * 8; lrow < std::min<int64_t>(gy * 8 + 8, w.n_rows) && !hot; lrow++)
+                    for (int64_t lrow = gy * RTAMD_BLOCK_H; lrow < std::min<int64_t>(gy * RTAMD_BLOCK_H + RTAMD_BLOCK_H, w.n_rows) && !hot; lrow++)
                         touches(lrow, gx * RTAMD_BLOCK_W, std::min<int64_t>(gx * RTAMD_BLOCK_W + RTAMD_BLOCK_W - 1, w.hsize - 1));
                 } else {
                     const int64_t p0 = grp * 64, p1 = std::min<int64_t>(p0 + 63, w.n_pixels - 1);

@@ -96,7 +96,8 @@ enum {
 };
 
 #define RTAMD_CSG_LIST_SMALL 12  // list length of the kernel variant for small CSG objects
-#define RTAMD_BLOCK_W 8          // width in pixels of a work-queue block (8 rows high)
+#define RTAMD_BLOCK_W 8          // a work-queue block: 64 pixels, this many wide (16 x 4 is no faster and writes as much)
+#define RTAMD_BLOCK_H (64 / RTAMD_BLOCK_W)
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
 #define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
 #define RTAMD_FRAME_F64 22   // doubles per saved shade-point frame
@@ -110,7 +111,7 @@ struct DWork {
     int32_t remaining;          // recursion budget of the primary rays
     int64_t n_pixels;           // pixels of this part (or number of custom rays)
     int64_t n_groups;           // the units of the work queue: groups of 64 pixels
-    int32_t gcols, n_rows;      // gcols != 0: a group is a block of 8 x 8 pixels, gcols blocks side by side, over the part's
+    int32_t gcols, n_rows;      // gcols != 0: a group is a block of RTAMD_BLOCK_W x RTAMD_BLOCK_H pixels, gcols blocks side by side, over the part's
                                 // n_rows rows; gcols == 0: a group is 64 consecutive pixels (ceil(n_pixels / 64) groups)
     int64_t group_stride;       // coprime to n_groups: queue position g stands for pixel group (g * stride) % n_groups
     const double* custom_rays;  // NULL: camera rays; else n_pixels x 6
