@@ -146,6 +146,28 @@ def main():
         dist.all_reduce(counts)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+
+    # Outside the timed region: a frame's two phases one after the other (nothing pipelined), slowest rank of each --
+    # the render kernel alone on its GPU, then the gather of the rows to rank 0 and their de-interleaving there.
+    cur = torch.cuda.current_stream()
+    phase = []
+    for _ in range(3):
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        buf = fg.begin()
+        e0.record()
+        ctx.render_rows(R, rank, world, mode, d_rgb=buf.data_ptr(), stream=cur.cuda_stream)
+        e1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fg.submit()
+        fg.finish()
+        torch.cuda.synchronize()
+        phase.append((e0.elapsed_time(e1), (time.perf_counter() - t1) * 1e3))
+    phase = torch.tensor(np.median(np.array(phase), axis=0), dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(phase, op=dist.ReduceOp.MAX)
+    render_alone_ms, gather_ms = float(phase[0]), float(phase[1])
     rays, shade_points, light_samples, containers = [float(x) / a.steps for x in counts]
 
     if rank == 0:
@@ -166,6 +188,8 @@ def main():
             "config": {"workload": f"{a.scene} scene graph at {W}x{H}, recursion budget 4, {a.mode} arithmetic",
                        "rays_per_frame": rays, "pixels": W * H, "row_tiles": f"cyclic, {R} rows", "parallelism": f"rows{world}",
                        "frames_in_flight": in_flight},
+            "phases": {"render_ms": render_alone_ms, "gather_ms": gather_ms,
+                       "note": "one frame at a time outside the timed region, slowest rank: render kernel, then gather to rank 0 + de-interleave"},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": achieved / (FP64_VALU_PEAK_TFLOPS * world), "traffic": traffic,
                          "kernel_ms": kernel_ms, "flops_per_ray": fpr, "algorithmic_flops_per_frame": flops,

@@ -399,6 +399,62 @@ def test_render_into_page_locked_memory(rt, gpu_ctx):
     assert np.array_equal(view, row)  # a view keeps the block alive
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (64, 1), (1, 64), (13, 9), (65, 17), (129, 8)])
+def test_ragged_frame_sizes(rt, oracle, gpu_ctx, w, h):
+    """Frames that are not whole blocks of pixels (a last block cut off on the right, at the bottom, or both;
+    fewer pixels than one wave has lanes): every pixel is written once and equals the oracle's."""
+    for name in ("reflect_refract", "cover"):
+        ref, ref8, _ = oracle.OracleScene(sg_path(name)).render(w, h, threads=4)
+        _upload(rt, gpu_ctx, name, w, h)
+        for mode, (m, tol) in _modes(rt).items():
+            gpu_ctx.reset_stats()
+            rgb, u8 = gpu_ctx.render(w, h, m, want_u8=True)
+            assert rgb.shape == (h, w, 3) and np.isfinite(rgb).all()
+            assert np.abs(rgb - ref).max() <= tol, (name, mode)
+            assert np.array_equal(u8, rt.quantize(rgb)) and (np.abs(u8.astype(int) - ref8.astype(int)) <= 1).mean() >= 0.999
+            assert gpu_ctx.stats().primary_rays == w * h
+
+
+EMPTY_CAMERA = """
+- add: camera
+  width: 24
+  height: 10
+  field-of-view: 1.2
+  from: [1, 2, -5]
+  to: [0, 0.5, 0]
+  up: [0, 1, 0]
+"""
+ONE_LIGHT = """
+- add: light
+  at: [-10, 10, -10]
+  intensity: [1, 1, 1]
+"""
+ONE_BALL = """
+- add: sphere
+  material:
+    color: [1, 0.2, 0.2]
+    reflective: 0.3
+- add: plane
+  transform:
+    - [translate, 0, -1, 0]
+"""
+
+
+def test_worlds_without_objects_or_without_lights(rt, oracle, gpu_ctx, tmp_path):
+    """World::intersect over no objects finds nothing (src/scene.rs:19-26 -> color_at's black, :53-63); shade_hit
+    over no lights adds nothing to black (src/scene.rs:28-51), reflections included."""
+    for text, lit in ((EMPTY_CAMERA + ONE_LIGHT, False), (EMPTY_CAMERA, False), (EMPTY_CAMERA + ONE_BALL, False),
+                      (EMPTY_CAMERA + ONE_LIGHT + ONE_BALL, True)):
+        o = _world(rt, oracle, gpu_ctx, tmp_path, text)
+        ref, _, _ = o.render(24, 10, threads=2)
+        for mode, (m, tol) in _modes(rt).items():
+            rgb, u8 = gpu_ctx.render(24, 10, m, want_u8=True)
+            assert np.abs(rgb - ref).max() <= tol
+            assert bool(rgb.any()) == lit and bool(u8.any()) == lit
+        rays = np.array([[0, 0, -5, 0, 0, 1], [0, 0, -5, 0, 1, 0]], dtype=float)
+        assert np.abs(gpu_ctx.color_at(rays, 4, rt.MODE_STRICT) - o.color_at(rays, 4)).max() <= STRICT_TOL
+
+
 def test_host_api_render_goes_through_the_gpu(rt):
     """Scene.render = Camera::render of the host library: flatten, upload, rtamd_render."""
     sc = rt.Scene.from_sg(sg_path("default_world"))
