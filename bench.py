@@ -70,6 +70,9 @@ def main():
                     help="frames rendering at once on a GPU (0: 1 on one GPU, 2 on several -- the tail of a frame, a few "
                          "long chains of dependent rays, then overlaps the start of the next; kernel durations, and with "
                          "them roofline.achieved, then include the time a kernel shares the GPU)")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="with one GPU: still go through the process group, the gather and the two frames in flight of the "
+                         "multi-GPU path (a rehearsal of that code on a one-GPU box; the figures are not comparable)")
     a = ap.parse_args()
 
     import torch
@@ -84,16 +87,22 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.rehearse_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_PORT" not in os.environ:  # a plain `python bench.py --rehearse-collective`
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     rt = importlib.import_module("ray-tracer_amd")
     rows_mod = importlib.import_module("ray-tracer_amd.rows")
     mode = rt.MODE_FAST if a.mode == "fast" else rt.MODE_STRICT
     sg = os.path.join(ROOT, "tests", "golden", "scenes", a.scene + ".sg")
     scene = rt.Scene.from_sg(sg).set_resolution(a.width, a.height)
-    in_flight = a.in_flight or (2 if world > 1 else 1)
+    in_flight = a.in_flight or (2 if use_dist else 1)
     flat = scene.flatten()
     ctxs = [rt.Context(local_rank) for _ in range(in_flight)]  # a context owns the scratch of one render under way
     for c in ctxs:
@@ -103,7 +112,7 @@ def main():
 
     if ctx.part_rows(R, rank, world) != len(rows_mod.part_row_indices(H, R, rank, world)):
         raise SystemExit("row partition of the library and of rows.py disagree")
-    fg = rows_mod.FrameGather(W, H, R, rank, world, dev)
+    fg = rows_mod.FrameGather(W, H, R, rank, world, dev, collective=use_dist)
     streams = [torch.cuda.current_stream()] if in_flight == 1 else [torch.cuda.Stream() for _ in range(in_flight)]
 
     def step(k, events=None):  # frame k's rows travel to rank 0 while the next frames render (rows.FrameGather)
@@ -118,7 +127,7 @@ def main():
             fg.submit()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -142,7 +151,7 @@ def main():
                            sum(st.shade_points for st in sts), sum(st.light_samples for st in sts),
                            sum(st.container_passes for st in sts)], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(counts)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
@@ -165,7 +174,7 @@ def main():
         torch.cuda.synchronize()
         phase.append((e0.elapsed_time(e1), (time.perf_counter() - t1) * 1e3))
     phase = torch.tensor(np.median(np.array(phase), axis=0), dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(phase, op=dist.ReduceOp.MAX)
     render_alone_ms, gather_ms = float(phase[0]), float(phase[1])
     rays, shade_points, light_samples, containers = [float(x) / a.steps for x in counts]
@@ -177,7 +186,7 @@ def main():
         achieved = flops / (kernel_ms * 1e-3) / 1e12  # per rank-kernel: flops of all ranks / slowest kernel
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_hbm_{a.scene}_{W}x{H}_{a.mode}.json")
-        if world == 1 and os.path.exists(pmc):
+        if world == 1 and not use_dist and os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         out = {
             "metric": "Mrays/sec (primary+secondary) & frame time, cover.yaml 4K, 1/2/4/8 MI355X",
@@ -187,7 +196,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.scene} scene graph at {W}x{H}, recursion budget 4, {a.mode} arithmetic",
                        "rays_per_frame": rays, "pixels": W * H, "row_tiles": f"cyclic, {R} rows", "parallelism": f"rows{world}",
-                       "frames_in_flight": in_flight},
+                       "frames_in_flight": in_flight, **({"rehearsal": "collective path on one rank"} if use_dist and world == 1 else {})},
             "phases": {"render_ms": render_alone_ms, "gather_ms": gather_ms,
                        "note": "one frame at a time outside the timed region, slowest rank: render kernel, then gather to rank 0 + de-interleave"},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
@@ -202,7 +211,7 @@ def main():
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(a, sg, frame, rt)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

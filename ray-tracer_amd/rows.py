@@ -33,8 +33,11 @@ class FrameGather:
     ``gather`` is the plain blocking form.
     """
 
-    def __init__(self, hsize, vsize, tile_rows, rank, world, device):
+    def __init__(self, hsize, vsize, tile_rows, rank, world, device, collective=None):
         self.rank, self.world = rank, world
+        # a single rank needs no exchange; `collective=True` makes it go through the gather all the same (a rehearsal
+        # of the multi-rank code with one process)
+        self._collective = world > 1 if collective is None else bool(collective)
         self.rows = [part_row_indices(vsize, tile_rows, p, world) for p in range(world)]
         max_rows = max(len(r) for r in self.rows)
         self.n_rows = len(self.rows[rank])
@@ -42,7 +45,7 @@ class FrameGather:
         self._pending = [None, None]
         self._cur = 0      # the slot begin() handed out last
         self._newest = 0   # the slot submitted last
-        if world == 1:
+        if not self._collective:
             self._locals = self._frames  # a single rank renders straight into the frame
         else:
             self._locals = [torch.empty((max_rows, hsize, 3), dtype=torch.float64, device=device) for _ in range(2)]
@@ -64,7 +67,7 @@ class FrameGather:
     def begin(self):
         """The buffer to render the next frame into (``local``); completes the frame its slot carried before."""
         self._cur ^= 1
-        if self.world > 1:
+        if self._collective:
             self._complete(self._cur)
         self.local = self._locals[self._cur]
         return self.local
@@ -73,12 +76,12 @@ class FrameGather:
         """Collective: starts the gather of the frame rendered into ``local``; returns at once.  With a device
         backend the transfer is ordered after the work queued so far on the current stream."""
         self._newest = self._cur
-        if self.world > 1:
+        if self._collective:
             self._pending[self._cur] = dist.gather(self.local, self._gathered[self._cur], dst=0, async_op=True)
 
     def finish(self):
         """Completes every frame under way, oldest first; rank 0 gets the newest frame (``frame``)."""
-        if self.world > 1:
+        if self._collective:
             self._complete(self._newest ^ 1)
             self._complete(self._newest)
         self.frame = self._frames[self._newest]

@@ -501,3 +501,24 @@ def test_error_paths(rt, gpu_ctx):
         fresh.render_rows(8, 2, 2, rt.MODE_FAST)  # part out of range
     assert fresh.color_at(np.zeros((0, 6)), 4).shape == (0, 3)
     fresh.close()
+
+
+def test_bench_multi_gpu_path_on_one_rank(monkeypatch, capsys):
+    """bench.py's multi-GPU code -- RCCL process group, barrier, two frames in flight on two streams, the
+    asynchronous gather to rank 0 and the de-interleaving there -- run with a single rank (in this process: a
+    process that holds the GPU starts no other program), and the frame it assembles checked against the oracle
+    by bench.py itself."""
+    import json
+    import sys
+    from conftest import ROOT
+    monkeypatch.syspath_prepend(ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--rehearse-collective", "--steps", "5", "--warmup", "2", "--width", "640",
+                                      "--height", "360", "--cpu-seconds", "1"])
+    bench = importlib.import_module("bench")
+    bench.main()
+    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["frames_in_flight"] == 2 and "rehearsal" in line["config"]
+    assert line["parity"]["u8_within_1_lsb"] >= 0.999 and line["parity"]["max_abs_f64"] <= FAST_TOL
+    assert line["phases"]["gather_ms"] > 0 and line["value"] > 0
