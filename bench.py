@@ -70,6 +70,10 @@ def main():
                     help="frames rendering at once on a GPU (0: 1 on one GPU, 2 on several -- the tail of a frame, a few "
                          "long chains of dependent rays, then overlaps the start of the next; kernel durations, and with "
                          "them roofline.achieved, then include the time a kernel shares the GPU)")
+    ap.add_argument("--rank0-share", default="auto",
+                    help="with several GPUs: 'equal', 'K0:K' (rank 0 holds K0 interleaved parts of the frame, every other rank K), "
+                         "or 'auto': a few such splits are tried during warm-up and the fastest is timed -- rank 0's rows do not "
+                         "travel, every other rank's cross one xGMI link")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="with one GPU: still go through the process group, the gather and the two frames in flight of the "
                          "multi-GPU path (a rehearsal of that code on a one-GPU box; the figures are not comparable)")
@@ -110,10 +114,14 @@ def main():
     ctx = ctxs[0]
     W, H, R = a.width, a.height, a.tile_rows
 
-    if ctx.part_rows(R, rank, world) != len(rows_mod.part_row_indices(H, R, rank, world)):
-        raise SystemExit("row partition of the library and of rows.py disagree")
-    fg = rows_mod.FrameGather(W, H, R, rank, world, dev, collective=use_dist)
+    def make_gather(k0, k):
+        g = rows_mod.FrameGather(W, H, R, rank, world, dev, collective=use_dist, shares=rows_mod.shares_for(world, k0, k))
+        if ctx.part_rows(R, g.part, g.n_parts, g.span) != g.n_rows:
+            raise SystemExit("row partition of the library and of rows.py disagree")
+        return g
+
     streams = [torch.cuda.current_stream()] if in_flight == 1 else [torch.cuda.Stream() for _ in range(in_flight)]
+    fg = None
 
     def step(k, events=None):  # frame k's rows travel to rank 0 while the next frames render (rows.FrameGather)
         j = k % in_flight
@@ -121,7 +129,7 @@ def main():
             buf = fg.begin()
             if events:
                 events[0].record()  # events bracket the render kernel itself, on the stream it is launched on
-            ctxs[j].render_rows(R, rank, world, mode, d_rgb=buf.data_ptr(), stream=streams[j].cuda_stream)
+            ctxs[j].render_rows(R, fg.part, fg.n_parts, mode, d_rgb=buf.data_ptr(), stream=streams[j].cuda_stream, span=fg.span)
             if events:
                 events[1].record()
             fg.submit()
@@ -131,6 +139,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # How the frame is shared out (untimed, part of the warm-up): every split is run for a few frames, pipelined as
+    # the timed steps are, and the fastest is kept.  All ranks see the same (max-reduced) times, so they agree.
+    trials = {}
+    if not use_dist or a.rank0_share == "equal":
+        share = (1, 1)
+    elif a.rank0_share != "auto":
+        share = tuple(int(x) for x in a.rank0_share.split(":"))
+    else:
+        for cand in ((1, 1), (1, 1), (3, 2), (2, 1), (5, 2), (3, 1)):  # (the first pass warms the GPU up; its time is replaced)
+            fg = make_gather(*cand)
+            for k in range(2 * in_flight):
+                step(k)
+            fg.finish()
+            sync()
+            t0 = time.perf_counter()
+            for k in range(8):
+                step(k)
+            fg.finish()
+            sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trials["%d:%d" % cand] = float(t[0]) / 8 * 1e3
+            fg = None
+        share = (1, 1)
+        best = min(trials, key=trials.get)
+        if trials[best] < 0.97 * trials["1:1"]:
+            share = tuple(int(x) for x in best.split(":"))
+    fg = make_gather(*share)
     for k in range(max(a.warmup, in_flight if a.warmup else 0)):
         step(k)
     fg.finish()
@@ -165,7 +201,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         buf = fg.begin()
         e0.record()
-        ctx.render_rows(R, rank, world, mode, d_rgb=buf.data_ptr(), stream=cur.cuda_stream)
+        ctx.render_rows(R, fg.part, fg.n_parts, mode, d_rgb=buf.data_ptr(), stream=cur.cuda_stream, span=fg.span)
         e1.record()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -195,7 +231,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.scene} scene graph at {W}x{H}, recursion budget 4, {a.mode} arithmetic",
-                       "rays_per_frame": rays, "pixels": W * H, "row_tiles": f"cyclic, {R} rows", "parallelism": f"rows{world}",
+                       "rays_per_frame": rays, "pixels": W * H, "parallelism": f"rows{world}",
+                       "row_tiles": f"cyclic, {R} rows" + ("" if world == 1 else f"; rank 0 holds {share[0]} of {fg.n_parts} interleaved parts, "
+                                                           f"every other rank {share[1]}"),
+                       **({"share_trials_ms_per_frame": trials} if trials else {}),
                        "frames_in_flight": in_flight, **({"rehearsal": "collective path on one rank"} if use_dist and world == 1 else {})},
             "phases": {"render_ms": render_alone_ms, "gather_ms": gather_ms,
                        "note": "one frame at a time outside the timed region, slowest rank: render kernel, then gather to rank 0 + de-interleave"},

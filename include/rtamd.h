@@ -151,11 +151,13 @@ typedef struct rtamd_scene {
 } rtamd_scene;
 
 /* Which rows of the frame a render call produces: rows are cut into tiles of `tile_rows`
- * consecutive rows, tile i belongs to part (i % n_parts); this call renders part `part`.
- * Output is compact: the part's rows in increasing order, hsize pixels each.
- * {tile_rows, 0, 1} = the whole frame. */
+ * consecutive rows, tile i belongs to part (i % n_parts); this call renders the `span` parts
+ * part .. part + span - 1 (span 0 means 1), so that callers can hold unequal shares of the frame and
+ * still keep the shares interleaved (the cost of a row varies a lot over a frame).
+ * Output is compact: the selected rows in increasing order, hsize pixels each.
+ * {tile_rows, 0, 1, 0} = the whole frame. */
 typedef struct rtamd_rows {
-    int32_t tile_rows, part, n_parts;
+    int32_t tile_rows, part, n_parts, span;
 } rtamd_rows;
 
 #define RTAMD_MODE_STRICT 0 /* no fused multiply-add, IEEE divide: the reference's f64 evaluation order */

@@ -58,7 +58,7 @@ class Stats(C.Structure):
 
 
 class Rows(C.Structure):
-    _fields_ = [("tile_rows", C.c_int32), ("part", C.c_int32), ("n_parts", C.c_int32)]
+    _fields_ = [("tile_rows", C.c_int32), ("part", C.c_int32), ("n_parts", C.c_int32), ("span", C.c_int32)]
 
 
 # every symbol include/rtamd.h declares
@@ -238,13 +238,14 @@ class Context:
     def last_error(self):
         return _gpu.rtamd_last_error(self._h).decode()
 
-    def part_rows(self, tile_rows, part, n_parts):
-        r = Rows(tile_rows, part, n_parts)
+    def part_rows(self, tile_rows, part, n_parts, span=1):
+        r = Rows(tile_rows, part, n_parts, span)
         return _gpu.rtamd_part_rows(self._h, C.byref(r))
 
-    def render_rows(self, tile_rows, part, n_parts, mode, d_rgb=0, d_rgb8=0, stream=0):
-        """Asynchronous; d_rgb / d_rgb8 are device addresses (e.g. ``tensor.data_ptr()``)."""
-        r = Rows(tile_rows, part, n_parts)
+    def render_rows(self, tile_rows, part, n_parts, mode, d_rgb=0, d_rgb8=0, stream=0, span=1):
+        """Asynchronous; d_rgb / d_rgb8 are device addresses (e.g. ``tensor.data_ptr()``).  Renders the tiles of
+        parts ``part .. part + span - 1`` of ``n_parts``."""
+        r = Rows(tile_rows, part, n_parts, span)
         self._chk(_gpu.rtamd_render_rows(self._h, C.byref(r), mode, C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None),
                                          C.c_void_p(stream or None)))
 

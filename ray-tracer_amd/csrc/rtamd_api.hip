@@ -44,7 +44,7 @@ struct rtamd_ctx {
     std::vector<std::array<int, 4>> costly;
     int32_t* d_order = nullptr;  // queue position -> group of 64 pixels, for the partition of the frame in order_key
     size_t order_cap = 0;
-    std::array<int64_t, 5> order_key{{-1, -1, -1, -1, -1}};
+    std::array<int64_t, 6> order_key{{-1, -1, -1, -1, -1, -1}};
     bool order_used = false;
     // device-side frame of rtamd_render (host destination), kept between calls
     double* d_out = nullptr;
@@ -577,7 +577,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
     // ---- where on the screen the costly leaves are (empty list: no preference)
     ctx->costly.clear();
-    ctx->order_key = {{-1, -1, -1, -1, -1}};
+    ctx->order_key = {{-1, -1, -1, -1, -1, -1}};
     {
         bool usable = cam_ok;
         for (int i = 0; usable && i < s->n_leaves; i++) {
@@ -633,10 +633,13 @@ static int64_t coprime_stride(int64_t n) {
 }
 
 static int64_t part_rows(int vsize, const rtamd_rows* r) {
-    if (!r || r->tile_rows <= 0 || r->n_parts <= 0 || r->part < 0 || r->part >= r->n_parts) return -1;
+    if (!r || r->tile_rows <= 0 || r->n_parts <= 0 || r->part < 0 || r->part >= r->n_parts || r->span < 0) return -1;
+    const int64_t span = std::max(1, r->span);
+    if (r->part + span > r->n_parts) return -1;
     int64_t rows = 0;
-    for (int64_t tile = r->part; tile * r->tile_rows < vsize; tile += r->n_parts)
-        rows += std::min<int64_t>(r->tile_rows, vsize - tile * r->tile_rows);
+    for (int64_t first = r->part; first * r->tile_rows < vsize; first += r->n_parts)
+        for (int64_t tile = first; tile < first + span && tile * r->tile_rows < vsize; tile++)
+            rows += std::min<int64_t>(r->tile_rows, vsize - tile * r->tile_rows);
     return rows;
 }
 
@@ -677,7 +680,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     if (!w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
         // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
         // The table depends on the partition of the frame only: it is kept until that changes.
-        const std::array<int64_t, 5> key{{w.hsize, w.vsize, w.tile_rows, w.part, w.n_parts}};
+        const std::array<int64_t, 6> key{{w.hsize, w.vsize, w.tile_rows, w.part, w.n_parts, w.span}};
         if (key != ctx->order_key) {
             ctx->order_used = false;
             std::vector<int32_t> first, rest;
@@ -686,8 +689,8 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
                 const int64_t grp = (j * w.group_stride) % w.n_groups;
                 bool hot = false;
                 auto touches = [&](int64_t lrow, int64_t xa, int64_t xb) {  // pixels xa..xb of row lrow of this part
-                    const int64_t tile = lrow / w.tile_rows;
-                    const int64_t py = (tile * w.n_parts + w.part) * w.tile_rows + (lrow - tile * w.tile_rows);
+                    const int64_t tile = lrow / w.tile_rows, cyc = tile / w.span;
+                    const int64_t py = (cyc * w.n_parts + w.part + (tile - cyc * w.span)) * w.tile_rows + (lrow - tile * w.tile_rows);
                     for (const auto& r : ctx->costly) hot |= py >= r[2] && py <= r[3] && xb >= r[0] && xa <= r[1];
                 };
                 if (w.gcols) {
@@ -737,7 +740,7 @@ int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* 
     if (nrows == 0) return RTAMD_OK;
     DWork w{};
     w.hsize = ctx->ds.cam.hsize, w.vsize = ctx->ds.cam.vsize;
-    w.tile_rows = rows->tile_rows, w.part = rows->part, w.n_parts = rows->n_parts;
+    w.tile_rows = rows->tile_rows, w.part = rows->part, w.n_parts = rows->n_parts, w.span = std::max(1, rows->span);
     w.remaining = ctx->ds.max_remaining;
     w.n_pixels = nrows * ctx->ds.cam.hsize;
     w.custom_rays = nullptr;
@@ -766,7 +769,7 @@ int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
     }
     double* d_rgb = h_rgb ? ctx->d_out : nullptr;
     uint8_t* d_u8 = h_rgb8 ? ctx->d_out8 : nullptr;
-    rtamd_rows all{ctx->ds.cam.vsize, 0, 1};
+    rtamd_rows all{ctx->ds.cam.vsize, 0, 1, 1};
     int rc = rtamd_render_rows(ctx, &all, mode, d_rgb, d_u8, nullptr);
     if (rc == RTAMD_OK) {
         hipError_t e = hipDeviceSynchronize();
@@ -803,7 +806,7 @@ int rtamd_color_at(rtamd_ctx* ctx, int mode, const double* h_rays, int64_t n, in
     HIPCHK(ctx, hipMemcpy(d_rays, h_rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
     DWork w{};
     w.hsize = ctx->ds.cam.hsize, w.vsize = ctx->ds.cam.vsize;
-    w.tile_rows = 1, w.part = 0, w.n_parts = 1;
+    w.tile_rows = 1, w.part = 0, w.n_parts = 1, w.span = 1;
     w.remaining = remaining;
     w.n_pixels = n;
     w.custom_rays = d_rays;

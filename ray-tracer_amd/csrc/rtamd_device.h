@@ -107,7 +107,7 @@ enum {
 struct DWork {
     // which pixels
     int32_t hsize, vsize;
-    int32_t tile_rows, part, n_parts;
+    int32_t tile_rows, part, n_parts, span;  // tiles i with i % n_parts in [part, part + span)
     int32_t remaining;          // recursion budget of the primary rays
     int64_t n_pixels;           // pixels of this part (or number of custom rays)
     int64_t n_groups;           // the units of the work queue: groups of 64 pixels

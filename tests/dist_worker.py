@@ -17,14 +17,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     w, h, tile_rows, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    rank0_parts, other_parts = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (1, 1)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rows_mod = importlib.import_module("ray-tracer_amd.rows")
     import oracle_lib
     o = oracle_lib.OracleScene(os.path.join(ROOT, "tests", "golden", "scenes", "cover.sg"))
-    fg = rows_mod.FrameGather(w, h, tile_rows, rank, world, torch.device("cpu"))
-    mine = rows_mod.part_row_indices(h, tile_rows, rank, world)
+    shares = rows_mod.shares_for(world, rank0_parts, other_parts)
+    fg = rows_mod.FrameGather(w, h, tile_rows, rank, world, torch.device("cpu"), shares=shares)
+    mine = rows_mod.part_row_indices(h, tile_rows, fg.part, fg.n_parts, fg.span)
     assert fg.n_rows == len(mine)
+    if (rank0_parts, other_parts) == (1, 1):
+        assert np.array_equal(mine, rows_mod.part_row_indices(h, tile_rows, rank, world))
     fg.local.fill_(float("nan"))
     if len(mine):
         pix = (mine[:, None] * w + np.arange(w)[None, :]).ravel()

@@ -31,15 +31,31 @@ def test_row_partition_is_a_cyclic_tiling(vsize, tile_rows, n_parts):
 
 def test_row_partition_rejects_bad_specs():
     rows_mod = importlib.import_module("ray-tracer_amd.rows")
-    for bad in [(10, 0, 0, 1), (10, 8, 2, 2), (10, 8, -1, 2), (10, 8, 0, 0)]:
+    for bad in [(10, 0, 0, 1), (10, 8, 2, 2), (10, 8, -1, 2), (10, 8, 0, 0), (10, 8, 1, 2, 2), (10, 8, 0, 2, 0)]:
         with pytest.raises(ValueError):
             rows_mod.part_row_indices(*bad)
 
 
-@pytest.mark.parametrize("world,w,h,tile_rows", [(2, 40, 27, 4), (3, 24, 10, 8)])
-def test_frame_gather_over_gloo(oracle, tmp_path, world, w, h, tile_rows):
+@pytest.mark.parametrize("vsize,tile_rows,world,rank0_parts,other_parts", [(2160, 8, 8, 2, 1), (2160, 8, 2, 5, 2), (37, 4, 3, 3, 2), (5, 8, 4, 2, 1)])
+def test_unequal_shares_tile_the_frame(vsize, tile_rows, world, rank0_parts, other_parts):
+    """Rank 0 holds more adjacent parts than the others: still every row exactly once, in interleaved tiles."""
+    rows_mod = importlib.import_module("ray-tracer_amd.rows")
+    n_parts, spans = rows_mod.shares_for(world, rank0_parts, other_parts)
+    assert n_parts == rank0_parts + (world - 1) * other_parts and len(spans) == world
+    parts = [rows_mod.part_row_indices(vsize, tile_rows, p, n_parts, s) for p, s in spans]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(vsize))
+    for (p, s), r in zip(spans, parts):
+        assert np.all(np.diff(r) > 0) and np.all(((r // tile_rows) % n_parts >= p) & ((r // tile_rows) % n_parts < p + s))
+    if vsize >= 4 * tile_rows * n_parts:
+        assert abs(len(parts[0]) / vsize - rank0_parts / n_parts) < 0.02
+
+
+@pytest.mark.parametrize("world,w,h,tile_rows,rank0_parts,other_parts",
+                         [(2, 40, 27, 4, 1, 1), (3, 24, 10, 8, 1, 1), (2, 40, 27, 2, 2, 1), (3, 24, 31, 2, 5, 2), (3, 24, 9, 4, 3, 1)])
+def test_frame_gather_over_gloo(oracle, tmp_path, world, w, h, tile_rows, rank0_parts, other_parts):
     """world processes each produce their rows; rank 0 must end with exactly the frame a single process
-    renders (the second case leaves rank 2 without any row)."""
+    renders (the second case leaves rank 2 without any row; the later ones give rank 0 a larger share than the
+    others, whose rows alone travel; in the last only rank 0 has rows)."""
     out = str(tmp_path / "frame.npy")
     port = _free_port()
     procs = []
@@ -47,7 +63,7 @@ def test_frame_gather_over_gloo(oracle, tmp_path, world, w, h, tile_rows):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(w), str(h),
-                                       str(tile_rows), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                       str(tile_rows), out, str(rank0_parts), str(other_parts)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
         try:

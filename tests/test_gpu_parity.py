@@ -355,21 +355,26 @@ def test_rows_partition_equals_whole_frame(rt, gpu_ctx):
     w, h = 160, 77
     _upload(rt, gpu_ctx, "cover", w, h)
     whole = torch.from_numpy(gpu_ctx.render(w, h, rt.MODE_FAST))
-    for tile_rows, n_parts in ((8, 2), (8, 8), (3, 5), (100, 2)):
+    # (tile_rows, world, parts of rank 0, parts of every other rank): equal shares, then rank 0 with a larger one
+    for tile_rows, world, k0, k in ((8, 2, 1, 1), (8, 8, 1, 1), (3, 5, 1, 1), (100, 2, 1, 1), (8, 2, 2, 1), (8, 3, 5, 2), (3, 4, 3, 1)):
+        n_parts, spans = rows_mod.shares_for(world, k0, k)
         frame = torch.full((h, w, 3), float("nan"), dtype=torch.float64)
-        for part in range(n_parts):
-            idx = rows_mod.part_row_indices(h, tile_rows, part, n_parts)
-            assert gpu_ctx.part_rows(tile_rows, part, n_parts) == len(idx)
+        for part, span in spans:
+            idx = rows_mod.part_row_indices(h, tile_rows, part, n_parts, span)
+            assert gpu_ctx.part_rows(tile_rows, part, n_parts, span) == len(idx)
             if len(idx) == 0:
                 continue
             buf = torch.empty((len(idx), w, 3), dtype=torch.float64, device="cuda")
             buf8 = torch.empty((len(idx), w, 3), dtype=torch.uint8, device="cuda")
             gpu_ctx.render_rows(tile_rows, part, n_parts, rt.MODE_FAST, d_rgb=buf.data_ptr(), d_rgb8=buf8.data_ptr(),
-                                stream=torch.cuda.current_stream().cuda_stream)
+                                stream=torch.cuda.current_stream().cuda_stream, span=span)
             torch.cuda.synchronize()
+            assert torch.isnan(frame[torch.from_numpy(idx)]).all()  # no row twice
             frame[torch.from_numpy(idx)] = buf.cpu()
             assert np.array_equal(buf8.cpu().numpy(), rt.quantize(buf.cpu().numpy()))
-        assert torch.equal(frame, whole), (tile_rows, n_parts)
+        assert torch.equal(frame, whole), (tile_rows, world, k0, k)
+    with pytest.raises(rt.RtamdError):
+        gpu_ctx.render_rows(8, 1, 2, rt.MODE_FAST, span=2)  # parts 1 and 2 of 2
 
 
 def test_render_is_deterministic_and_contexts_are_independent(rt, gpu_ctx):
