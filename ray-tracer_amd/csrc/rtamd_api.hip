@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <functional>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -329,6 +331,156 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
     }
     if ((rc = upload(ctx, boxes.data(), boxes.size(), &d.mesh_box))) return rc;
+    // Runs of triangles for the traversal.  Consecutive MESH leaves that differ in nothing but their triangles (one
+    // object cut into runs by the host) are one pool of triangles, and nothing says which triangle has to be tested
+    // in which run: the pool is cut again by median splits along the longest axis of its centroids' bounds, so that
+    // a run's box is compact whatever order the file had.  The traversal reads this copy of the triangles; every
+    // triangle keeps the intersection key of its place in the original order (leaf << RTAMD_KEY_SHIFT | slot), which
+    // is what decides between equal t (src/scene.rs:19-26: stable sorts) and what shading looks the triangle up by.
+    // CSG children are tested from the leaf table and keep the original runs.
+    std::vector<double> tri_sorted(s->tri_geom, s->tri_geom + (size_t)s->n_tris * 9);
+    std::vector<int32_t> tri_key((size_t)s->n_tris, 0);
+    std::vector<double> run_box(boxes);
+    std::vector<int32_t> run_start((size_t)s->n_leaves, 0), run_count((size_t)s->n_leaves, 0);
+    {
+        std::vector<char> in_csg((size_t)s->n_leaves, 0);
+        for (int r = 0; r < s->n_csg_roots; r++)
+            for (int l = s->csg_roots[r].leaf_lo; l < s->csg_roots[r].leaf_hi; l++) in_csg[(size_t)l] = 1;
+        for (int i = 0; i < s->n_leaves; i++) {
+            const rtamd_leaf& L = s->leaves[i];
+            if (L.kind != RTAMD_MESH) continue;
+            run_start[(size_t)i] = L.tri_start, run_count[(size_t)i] = L.tri_count;
+            for (int k = 0; k < L.tri_count; k++) tri_key[(size_t)L.tri_start + k] = (int32_t)(((uint32_t)i << RTAMD_KEY_SHIFT) | (uint32_t)k);
+        }
+        const std::vector<int32_t> orig_key(tri_key);
+        auto same_object = [&](int a, int b) {
+            const rtamd_leaf &A = s->leaves[a], &B = s->leaves[b];
+            return B.kind == RTAMD_MESH && !in_csg[(size_t)b] && has_box[(size_t)b] && std::memcmp(A.w2o, B.w2o, sizeof A.w2o) == 0 &&
+                   A.flags == B.flags && A.material == B.material && A.eq_class == B.eq_class && A.chain_len == B.chain_len &&
+                   std::memcmp(s->chain + (size_t)A.chain_start * 12, s->chain + (size_t)B.chain_start * 12, (size_t)A.chain_len * 12 * sizeof(double)) == 0;
+        };
+        for (int i = 0; i < s->n_leaves;) {
+            const rtamd_leaf& L = s->leaves[i];
+            int j = i + 1;
+            if (L.kind == RTAMD_MESH && !in_csg[(size_t)i] && has_box[(size_t)i])
+                while (j < s->n_leaves && same_object(i, j) && s->leaves[j].tri_start == s->leaves[j - 1].tri_start + s->leaves[j - 1].tri_count) j++;
+            if (j - i < 2) {
+                i = j;
+                continue;
+            }
+            const int first = L.tri_start, total = s->leaves[j - 1].tri_start + s->leaves[j - 1].tri_count - first;
+            int cap = 1;  // triangles per run: what the host chose
+            for (int l = i; l < j; l++) cap = std::max(cap, s->leaves[l].tri_count);
+            // object -> world for the corners (as for the boxes above)
+            const double* m = L.w2o;
+            const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+            const double inv[9] = {(m[5] * m[10] - m[6] * m[9]) / det, (m[2] * m[9] - m[1] * m[10]) / det, (m[1] * m[6] - m[2] * m[5]) / det,
+                                   (m[6] * m[8] - m[4] * m[10]) / det, (m[0] * m[10] - m[2] * m[8]) / det, (m[2] * m[4] - m[0] * m[6]) / det,
+                                   (m[4] * m[9] - m[5] * m[8]) / det, (m[1] * m[8] - m[0] * m[9]) / det, (m[0] * m[5] - m[1] * m[4]) / det};
+            std::vector<double> tlo((size_t)total * 3), thi((size_t)total * 3), cen((size_t)total * 3);
+            for (int t = 0; t < total; t++) {
+                const double* g = s->tri_geom + ((size_t)first + t) * 9;
+                for (int k = 0; k < 3; k++) tlo[(size_t)t * 3 + k] = INFINITY, thi[(size_t)t * 3 + k] = -INFINITY;
+                for (int v = 0; v < 3; v++) {
+                    double p[3];
+                    for (int k = 0; k < 3; k++) p[k] = (v == 0 ? g[k] : g[k] + g[3 * v + k]) - m[4 * k + 3];
+                    for (int k = 0; k < 3; k++) {
+                        const double w = inv[3 * k] * p[0] + inv[3 * k + 1] * p[1] + inv[3 * k + 2] * p[2];
+                        tlo[(size_t)t * 3 + k] = std::min(tlo[(size_t)t * 3 + k], w), thi[(size_t)t * 3 + k] = std::max(thi[(size_t)t * 3 + k], w);
+                    }
+                }
+                for (int k = 0; k < 3; k++) cen[(size_t)t * 3 + k] = 0.5 * (tlo[(size_t)t * 3 + k] + thi[(size_t)t * 3 + k]);
+            }
+            std::vector<int> order((size_t)total);
+            for (int t = 0; t < total; t++) order[(size_t)t] = t;
+            std::vector<std::pair<int, int>> runs;  // [begin, end) in `order`
+            std::function<void(int, int)> split = [&](int b, int e) {
+                if (e - b <= cap) {
+                    runs.push_back({b, e});
+                    return;
+                }
+                // Of the three axes and of every cut that leaves whole runs on the left (no more runs than before), the
+                // one with the least sum over both sides of box surface x triangles: what a ray that enters a box pays.
+                auto surface = [](const double* lo, const double* hi) {
+                    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                    return 2.0 * (dx * dy + dy * dz + dx * dz);
+                };
+                const int n = e - b;
+                double best_cost = INFINITY;
+                int best_axis = 0, half = cap;
+                std::vector<int> sorted_by[3];
+                std::vector<double> right((size_t)n + 1);
+                for (int ax = 0; ax < 3; ax++) {
+                    std::vector<int>& o = sorted_by[ax];
+                    o.assign(order.begin() + b, order.begin() + e);
+                    std::stable_sort(o.begin(), o.end(), [&](int x, int y) { return cen[(size_t)x * 3 + ax] < cen[(size_t)y * 3 + ax]; });
+                    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    for (int q = n - 1; q >= 0; q--) {  // right[q]: surface of the box of o[q..n)
+                        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], tlo[(size_t)o[(size_t)q] * 3 + k]), hi[k] = std::max(hi[k], thi[(size_t)o[(size_t)q] * 3 + k]);
+                        right[(size_t)q] = surface(lo, hi);
+                    }
+                    for (int k = 0; k < 3; k++) lo[k] = INFINITY, hi[k] = -INFINITY;
+                    for (int q = 0; q + 1 < n; q++) {
+                        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], tlo[(size_t)o[(size_t)q] * 3 + k]), hi[k] = std::max(hi[k], thi[(size_t)o[(size_t)q] * 3 + k]);
+                        if ((q + 1) % cap != 0) continue;
+                        const double cost = surface(lo, hi) * (q + 1) + right[(size_t)q + 1] * (n - q - 1);
+                        if (cost < best_cost) best_cost = cost, best_axis = ax, half = q + 1;
+                    }
+                }
+                std::copy(sorted_by[best_axis].begin(), sorted_by[best_axis].end(), order.begin() + b);
+                split(b, b + half);
+                split(b + half, e);
+            };
+            split(0, total);
+            if ((int)runs.size() > j - i) {  // cannot happen (ceil(total / cap) runs); keep the original runs if it does
+                i = j;
+                continue;
+            }
+            if (getenv("RTAMD_UPLOAD_DUMP")) {  // diagnostic
+                auto area = [&](int l, const std::vector<double>& bx) {
+                    const double* q = &bx[(size_t)l * 6];
+                    const double dx = q[3] - q[0], dy = q[4] - q[1], dz = q[5] - q[2];
+                    return dx > 0 ? 2 * (dx * dy + dy * dz + dx * dz) : 0.0;
+                };
+                double before = 0;
+                for (int l = i; l < j; l++) before += area(l, boxes);
+                fprintf(stderr, "[rtamd upload] pool of %d triangles in leaves %d..%d: %zu runs of <= %d, box area before %.4f\n", total, i, j - 1,
+                        runs.size(), cap, before);
+            }
+            int pos = first;
+            for (int l = i; l < j; l++) {
+                const size_t r = (size_t)(l - i);
+                double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                run_start[(size_t)l] = pos, run_count[(size_t)l] = 0;
+                if (r < runs.size()) {
+                    for (int q = runs[r].first; q < runs[r].second; q++, pos++) {
+                        const int t = order[(size_t)q];
+                        std::memcpy(&tri_sorted[(size_t)pos * 9], s->tri_geom + ((size_t)first + t) * 9, 9 * sizeof(double));
+                        tri_key[(size_t)pos] = orig_key[(size_t)first + t];
+                        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], tlo[(size_t)t * 3 + k]), hi[k] = std::max(hi[k], thi[(size_t)t * 3 + k]);
+                    }
+                    run_count[(size_t)l] = runs[r].second - runs[r].first;
+                }
+                for (int k = 0; k < 3; k++) {  // (an empty run gets an empty box: lo = inf, hi = -inf)
+                    const double pad = 1e-6 * std::max({hi[k] - lo[k], std::fabs(lo[k]), std::fabs(hi[k]), 1e-30});
+                    run_box[(size_t)l * 6 + k] = run_count[(size_t)l] ? lo[k] - pad : INFINITY;
+                    run_box[(size_t)l * 6 + 3 + k] = run_count[(size_t)l] ? hi[k] + pad : -INFINITY;
+                }
+            }
+            if (getenv("RTAMD_UPLOAD_DUMP")) {
+                double after = 0;
+                for (int l = i; l < j; l++) {
+                    const double* q = &run_box[(size_t)l * 6];
+                    const double dx = q[3] - q[0], dy = q[4] - q[1], dz = q[5] - q[2];
+                    after += dx > 0 ? 2 * (dx * dy + dy * dz + dx * dz) : 0.0;
+                }
+                fprintf(stderr, "[rtamd upload]   box area after %.4f\n", after);
+            }
+            i = j;
+        }
+    }
+    if ((rc = upload(ctx, tri_sorted.data(), tri_sorted.size(), &d.tri_sorted))) return rc;
+    if ((rc = upload(ctx, tri_key.data(), tri_key.size(), &d.tri_key))) return rc;
     // The pixel rectangle (x0, x1, y0, y1) that bounds what the camera sees of a world-space box; false when there is
     // none (part of the box at or behind the camera, degenerate camera).
     const rtamd_camera& C = s->camera;
@@ -386,11 +538,11 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
         D.p0 = L.p0, D.p1 = L.p1;
         if (L.kind == RTAMD_MESH) {
-            int32_t tr[2] = {L.tri_start, L.tri_count};
+            int32_t tr[2] = {run_start[(size_t)leaf], run_count[(size_t)leaf]};  // in tri_sorted / tri_key
             std::memcpy(&D.p0, tr, sizeof tr);
             // the traversal needs the bounds for every run and the matrix only for the runs a ray comes near:
             // the bounds take the matrix's place in the record, the matrix stays in the leaf table
-            std::memcpy(D.w2o, &boxes[(size_t)leaf * 6], 6 * sizeof(double));
+            std::memcpy(D.w2o, &run_box[(size_t)leaf * 6], 6 * sizeof(double));
             for (int k = 6; k < 12; k++) D.w2o[k] = 0.0;
         }
         D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
@@ -467,7 +619,8 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                     std::memcpy(sc, &v.p0, sizeof sc);
                     for (int q = sc[0]; q < sc[0] + sc[1]; q++) add_dir(&cone_dirs[(size_t)q * 9]);
                 }
-                const double* b = (v.kind_flags & 0xffu) == DVISIT_BOUNDS ? v.w2o : &boxes[(size_t)v.unit * 6];
+                const uint32_t vk = v.kind_flags & 0xffu;  // bounds records and runs of triangles hold their box themselves
+                const double* b = vk == DVISIT_BOUNDS || vk == RTAMD_MESH ? v.w2o : &boxes[(size_t)v.unit * 6];
                 for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], b[k]), hi[k] = std::max(hi[k], b[3 + k]);
             }
             for (int k = 0; k < 3; k++) B.w2o[k] = lo[k], B.w2o[3 + k] = hi[k];

@@ -71,6 +71,8 @@ struct DScene {
     const DShade* shade;  // one per leaf
     const double* chain;
     const double* tri_geom;
+    const double* tri_sorted;  // the same triangles in the order of the runs the traversal tests (9 doubles each)
+    const int32_t* tri_key;    // per triangle of tri_sorted: leaf << RTAMD_KEY_SHIFT | slot of its place in tri_geom
     const double* cone_dirs;  // 9 doubles each: the 3x3 part of the world -> object matrix of a cone (lists that bounds records point into)
     const double* mesh_box;  // per leaf 6 doubles: enlarged world-space bounds (lo xyz, hi xyz) of a MESH leaf's triangles
     const double* tri_normals;

@@ -347,6 +347,50 @@ def test_both_forms_of_the_triangle_test_give_the_same_bits(rt, gpu_ctx, mode):
     assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2])
 
 
+def _tied_triangles_obj(seed=7, n=150):
+    """An OBJ whose every triangle is there twice, with different vertex normals, the copies far apart in the file:
+    the two intersections of a ray have the same t to the bit, and which one shades the pixel is decided by the
+    order of the file alone (stable sorts, src/scene.rs:19-26; fan triangulation and smooth faces, src/obj.rs:62-80)."""
+    rng = np.random.default_rng(seed)
+    lines, faces = [], []
+    for i in range(n):
+        c = rng.uniform([-3, -2, 0.2], [3, 2, 3])
+        pts = c + rng.uniform(-0.9, 0.9, (3, 3))
+        for p_ in pts:
+            lines.append("v %.6f %.6f %.6f" % tuple(p_))
+        for k in range(2):  # two sets of normals
+            for _ in range(3):
+                nrm = rng.normal(size=3)
+                lines.append("vn %.6f %.6f %.6f" % tuple(nrm / np.linalg.norm(nrm)))
+        v = 3 * i + 1
+        for k in range(2):
+            nn = 6 * i + 3 * k + 1
+            faces.append("f %d//%d %d//%d %d//%d" % (v, nn, v + 1, nn + 1, v + 2, nn + 2))
+    order = rng.permutation(len(faces))
+    return "\n".join(lines + [faces[i] for i in order]) + "\n"
+
+
+@pytest.mark.parametrize("few", ["0", "64"])
+def test_triangles_that_tie_keep_the_order_of_the_file(rt, oracle, gpu_ctx, tmp_path, few):
+    """The traversal tests the triangles of an object in runs sorted by place, not in the order of the file; among
+    intersections with equal t the reference takes the first of the file.  Both forms of the triangle test."""
+    obj = tmp_path / "tied.obj"
+    obj.write_text(_tied_triangles_obj())
+    sc = rt.Scene.builtin("teapot_room", str(obj)).set_resolution(96, 48)
+    sg = str(tmp_path / "tied.sg")
+    sc.save_sg(sg)
+    ref, ref8, _ = oracle.OracleScene(sg).render(96, 48, threads=8)
+    gpu_ctx.upload(sc.flatten())
+    try:
+        os.environ["RTAMD_MESH_FEW"] = few
+        for mode, (m, tol) in _modes(rt).items():
+            rgb, u8 = gpu_ctx.render(96, 48, m, want_u8=True)
+            assert np.abs(rgb - ref).max() <= tol, (mode, few)
+            assert (np.abs(u8.astype(int) - ref8.astype(int)) <= 1).mean() >= 0.999
+    finally:
+        os.environ.pop("RTAMD_MESH_FEW", None)
+
+
 # ------------------------------------------------------------------ boundary behaviour
 def test_rows_partition_equals_whole_frame(rt, gpu_ctx):
     """Rendering the frame in parts (what the ranks of a multi-GPU job do) gives the bits of one call."""
