@@ -373,7 +373,9 @@ def _tied_triangles_obj(seed=7, n=150):
 @pytest.mark.parametrize("few", ["0", "64"])
 def test_triangles_that_tie_keep_the_order_of_the_file(rt, oracle, gpu_ctx, tmp_path, few):
     """The traversal tests the triangles of an object in runs sorted by place, not in the order of the file; among
-    intersections with equal t the reference takes the first of the file.  Both forms of the triangle test."""
+    intersections with equal t the reference takes the first of the file.  Copies of one triangle stay in the
+    order of the file inside the sorted runs (the sorts are stable), and every triangle carries the key of its
+    place in the file for ties between different triangles.  Both forms of the triangle test."""
     obj = tmp_path / "tied.obj"
     obj.write_text(_tied_triangles_obj())
     sc = rt.Scene.builtin("teapot_room", str(obj)).set_resolution(96, 48)
