@@ -554,7 +554,8 @@ def test_error_paths(rt, gpu_ctx):
     fresh.close()
 
 
-def test_bench_multi_gpu_path_on_one_rank(monkeypatch, capsys):
+@pytest.mark.parametrize("share", ["auto", "3:2"])
+def test_bench_multi_gpu_path_on_one_rank(monkeypatch, capsys, share):
     """bench.py's multi-GPU code -- RCCL process group, barrier, two frames in flight on two streams, the
     asynchronous gather to rank 0 and the de-interleaving there -- run with a single rank (in this process: a
     process that holds the GPU starts no other program), and the frame it assembles checked against the oracle
@@ -566,10 +567,11 @@ def test_bench_multi_gpu_path_on_one_rank(monkeypatch, capsys):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--rehearse-collective", "--steps", "5", "--warmup", "2", "--width", "640",
-                                      "--height", "360", "--cpu-seconds", "1"])
+                                      "--height", "360", "--cpu-seconds", "1", "--rank0-share", share])
     bench = importlib.import_module("bench")
     bench.main()
     line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["frames_in_flight"] == 2 and "rehearsal" in line["config"]
     assert line["parity"]["u8_within_1_lsb"] >= 0.999 and line["parity"]["max_abs_f64"] <= FAST_TOL
     assert line["phases"]["gather_ms"] > 0 and line["value"] > 0
+    assert ("share_trials_ms_per_frame" in line["config"]) == (share == "auto")
