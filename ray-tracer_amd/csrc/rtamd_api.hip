@@ -28,7 +28,7 @@ struct rtamd_ctx {
     int num_cus = 0;
     std::string err;
     bool have_scene = false, has_csg = false;
-    int variant = 0;  // kernel variant of the uploaded scene: base (0 plain, 1 triangles, 2 CSG, 3 small CSG) + 4 with axis-aligned cubes + 8 with cylinders or cones + 16 with bounds records
+    int variant = 0;  // kernel variant of the uploaded scene: base (0 plain, 1 triangles, 2 CSG, 3 small CSG) + 4 with axis-aligned cubes + 8 with cylinders or cones + 16 with bounds records + 32 CSG without triangles
     DScene ds{};
     std::vector<void*> scene_bufs;
     unsigned long long* d_queue = nullptr;
@@ -36,7 +36,7 @@ struct rtamd_ctx {
     double* d_frames = nullptr;
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
-    int max_blocks[2][32] = {};  // [mode][variant]
+    int max_blocks[2][64] = {};  // [mode][variant]
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -101,7 +101,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
-    for (int v = 0; v < 32; v++) {
+    for (int v = 0; v < 64; v++) {
         int b = 0;
         if ((e = rtamd_occupancy_strict(v, &b)) != hipSuccess) return bail("occupancy(strict)", e);
         ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, b) * ctx->num_cus;
@@ -110,7 +110,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     }
     int mb = 0;
     for (int m = 0; m < 2; m++)
-        for (int c = 0; c < 32; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
+        for (int c = 0; c < 64; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
     if ((e = hipMalloc(&ctx->d_queue, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(queue)", e);
@@ -754,6 +754,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     ctx->has_csg = s->n_csg_roots > 0;
     bool has_bounds = false;
     ctx->variant = ctx->has_csg ? (csg_small ? 3 : 2) : (s->n_tris > 0 ? 1 : 0);
+    if (ctx->has_csg && s->n_tris == 0) ctx->variant |= 32;  // the CSG kernels without the code for triangles
     if (!ctx->has_csg)  // the CSG kernels are built without the slab code
         for (int i = 0; i < s->n_leaves; i++) {
             if (dl[i].kind == RTAMD_CUBE && (dl[i].flags & DLEAF_DIAG)) ctx->variant |= 4;
