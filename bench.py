@@ -6,9 +6,9 @@
         bench.py --gpus N --steps K --warmup W
 
 A step = one frame of the workload (default: scenes/cover.yaml of the reference at 3840x2160, recursion
-budget 4), rendered with the scene already resident in HBM: every rank renders its cyclic row tiles
-(tile i -> rank i % N), the float64 frame (the reference's Canvas) is gathered on rank 0 over RCCL and
-put back in row order.  Rank 0 prints ONE JSON line.  `value` = rays traced by all ranks per second
+budget 4), rendered with the scene already resident in HBM: every rank renders its interleaved row tiles
+(tile i -> part i % n_parts; a rank holds one part, rank 0 possibly more: --rank0-share), the float64 frame
+(the reference's Canvas) is gathered on rank 0 over RCCL and put back in row order.  Rank 0 prints ONE JSON line.  `value` = rays traced by all ranks per second
 (primary, reflection, refraction and shadow rays; the n1/n2 container passes are not counted).
 """
 import argparse
