@@ -162,10 +162,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             trials["%d:%d" % cand] = float(t[0]) / 8 * 1e3
             fg = None
-        share = (1, 1)
-        best = min(trials, key=trials.get)
-        if trials[best] < 0.97 * trials["1:1"]:
-            share = tuple(int(x) for x in best.split(":"))
+        share = rows_mod.pick_share(trials)
     fg = make_gather(*share)
     for k in range(max(a.warmup, in_flight if a.warmup else 0)):
         step(k)

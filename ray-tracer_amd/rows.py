@@ -33,6 +33,16 @@ def shares_for(world, rank0_parts=1, other_parts=1):
     return rank0_parts + (world - 1) * other_parts, spans
 
 
+def pick_share(trial_ms, margin=0.97):
+    """From measured ms per frame of the splits tried ({"k0:k": ms}, the equal split "1:1" among them): the
+    fastest one if it beats the equal split by the margin, else the equal split.  Returns (k0, k)."""
+    best = min(trial_ms, key=lambda s: (trial_ms[s], s))
+    if best != "1:1" and trial_ms[best] < margin * trial_ms["1:1"]:
+        k0, k = best.split(":")
+        return int(k0), int(k)
+    return 1, 1
+
+
 class FrameGather:
     """Buffers and the exchange step of one rank, for two frames in flight.
 

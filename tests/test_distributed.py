@@ -11,6 +11,14 @@ import pytest
 from conftest import ROOT, sg_path
 
 
+def test_share_is_changed_only_for_a_clear_gain():
+    rows_mod = importlib.import_module("ray-tracer_amd.rows")
+    assert rows_mod.pick_share({"1:1": 1.50, "3:2": 1.30, "2:1": 1.10, "5:2": 1.12, "3:1": 1.20}) == (2, 1)
+    assert rows_mod.pick_share({"1:1": 1.00, "3:2": 0.99, "2:1": 0.98}) == (1, 1)  # within the noise of a few frames
+    assert rows_mod.pick_share({"1:1": 1.00}) == (1, 1)
+    assert rows_mod.pick_share({"1:1": 2.0, "2:1": 1.0, "3:1": 1.0}) == (2, 1)  # a tie: the same choice on every rank
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
