@@ -182,7 +182,8 @@ const char* rtamd_last_error(const rtamd_ctx* ctx); /* ctx may be NULL: creation
 
 /* Replaces the scene state Camera::render reads (World after refresh_parents, Camera):
  * src/scene.rs:236-238. Validates indices and limits, then copies to the device. A scene that fails
- * validation leaves the previously uploaded one (if any) in place. */
+ * validation, or whose copy to the device fails, leaves the previously uploaded one (if any) in place.
+ * Clears the counters of rtamd_get_stats. */
 int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* scene);
 
 /* Number of rows / pixels a rows-spec selects for the uploaded scene. */
@@ -192,7 +193,11 @@ int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows);
  * ray_for_pixel + color_at(ray, max_remaining) + Canvas::write_pixel.
  * d_rgb: device pointer, 3 doubles per pixel (Canvas.pixels, src/tuple.rs:309-313), may be NULL;
  * d_rgb8: device pointer, 3 bytes per pixel quantised as `From<Color> for (usize,usize,usize)`
- * (src/tuple.rs:226-237), may be NULL. Asynchronous on `stream` (a hipStream_t, NULL = default). */
+ * (src/tuple.rs:226-237), may be NULL. Asynchronous on `stream` (a hipStream_t, NULL = default).
+ * A context owns the scratch of ONE render under way (work queue, frame stacks, counters, timing events): start
+ * the next render, rtamd_color_at or upload of the same context on the same stream, or after this one has finished;
+ * to overlap frames on one GPU use one context per frame in flight.  The call itself may allocate and wait for the
+ * device the first time a partition of the frame is used (it builds the work-queue order for it). */
 int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream);
 
 /* Camera::render for the whole frame into host memory (either pointer may be NULL). Blocking.

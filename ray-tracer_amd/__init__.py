@@ -138,9 +138,9 @@ class Flat:
         """The ``rtamd_scene`` as a ctypes structure (pointers stay valid while this object lives)."""
         return abi.SceneStruct.from_address(self.view)
 
-    def __del__(self):
-        if getattr(self, "_h", None) and _host is not None:  # module globals are gone at interpreter exit
-            _host.rth_free_flat(self._h)
+    def __del__(self, _free=_host.rth_free_flat):  # bound now: module globals are gone at interpreter exit
+        if getattr(self, "_h", None):
+            _free(self._h)
             self._h = None
 
 
@@ -199,9 +199,9 @@ class Scene:
             raise _host_err()
         return (rgb, u8, st) if want_u8 else (rgb, st)
 
-    def __del__(self):
-        if getattr(self, "_h", None) and _host is not None:
-            _host.rth_free_scene(self._h)
+    def __del__(self, _free=_host.rth_free_scene):
+        if getattr(self, "_h", None):
+            _free(self._h)
             self._h = None
 
 
@@ -274,9 +274,9 @@ class Context:
     def reset_stats(self):
         self._chk(_gpu.rtamd_reset_stats(self._h))
 
-    def close(self):
-        if getattr(self, "_h", None) and _gpu is not None:
-            _gpu.rtamd_ctx_destroy(self._h)
+    def close(self, _destroy=_gpu.rtamd_ctx_destroy):
+        if getattr(self, "_h", None):
+            _destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -289,9 +289,9 @@ class _Pinned:
     def __init__(self, ptr):
         self.ptr = ptr
 
-    def __del__(self):
-        if self.ptr and _gpu is not None:
-            _gpu.rtamd_host_free(self.ptr)
+    def __del__(self, _free=_gpu.rtamd_host_free):
+        if self.ptr:
+            _free(self.ptr)
             self.ptr = None
 
 

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <array>
 #include <functional>
+#include <mutex>
+#include <new>
 #include <utility>
 #include <string>
 #include <vector>
@@ -52,6 +54,8 @@ struct rtamd_ctx {
     double* d_out = nullptr;
     uint8_t* d_out8 = nullptr;
     size_t out_cap = 0, out8_cap = 0;
+    unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope `scratch` array
+    unsigned long long ovf_seen = 0;          // CSG list overflows counted up to the last check by rtamd_render
 };
 
 static std::string g_create_err;
@@ -94,7 +98,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     ctx->device = device;
     auto bail = [&](const char* what, hipError_t err) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(err);
-        delete ctx;
+        rtamd_ctx_destroy(ctx);  // releases whatever exists so far
         return RTAMD_E_HIP;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
@@ -178,7 +182,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if (s->n_lights < 0 || s->n_lights > RTAMD_MAX_LIGHTS) return fail(ctx, RTAMD_E_LIMIT, "too many lights");
     if (s->n_leaves >= (1 << (31 - RTAMD_KEY_SHIFT))) return fail(ctx, RTAMD_E_LIMIT, "too many leaves");
     if (s->n_leaves < 0 || s->n_chain < 0 || s->n_tris < 0 || s->n_materials < 0 || s->n_csg_nodes < 0 || s->n_csg_roots < 0 ||
-        s->n_visits < 0)
+        s->n_visits < 0 || s->n_classes < 0)
         return fail(ctx, RTAMD_E_INVALID, "negative count");
     if ((s->n_lights && !s->lights) || (s->n_leaves && !s->leaves) || (s->n_chain && !s->chain) ||
         (s->n_tris && (!s->tri_geom || !s->tri_normals)) || (s->n_materials && !s->materials) ||
@@ -200,8 +204,39 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 return fail(ctx, RTAMD_E_INVALID, "mesh triangle range out of range");
             slots = L.tri_count;
         } else {
+static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s);
+
             slots = 4;
         }
+    try {  // the host-side tables below are std::vectors: nothing may unwind across the C boundary
+        return scene_upload(ctx, s);
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, RTAMD_E_LIMIT, "scene upload: out of host memory");
+    } catch (...) {
+        return fail(ctx, RTAMD_E_INVALID, "scene upload: unexpected failure while building the device tables");
+    }
+}
+
+// Keeps the previously uploaded scene alive until the new one is complete on the device: a failure on the way
+// frees what the new one had got so far and puts the old buffers back.
+namespace {
+struct UploadGuard {
+    rtamd_ctx* ctx;
+    std::vector<void*> old;
+    bool done = false;
+    explicit UploadGuard(rtamd_ctx* c) : ctx(c) { old.swap(c->scene_bufs); }
+    ~UploadGuard() {
+        if (done) {
+            for (void* p : old) (void)hipFree(p);
+        } else {
+            for (void* p : ctx->scene_bufs) (void)hipFree(p);
+            ctx->scene_bufs.swap(old);
+        }
+    }
+};
+}  // namespace
+
+static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         DLeaf& D = dl[i];
         std::memset(&D, 0, sizeof D);
         std::memcpy(D.w2o, L.w2o, sizeof L.w2o);
@@ -211,6 +246,7 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         const double* m = L.w2o;
         if (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0 && m[0] != 0.0 && m[5] != 0.0 &&
             m[10] != 0.0) {
+    if (s->n_classes > std::max(s->n_leaves, 1)) return fail(ctx, RTAMD_E_INVALID, "more equality classes than leaves");
             D.flags |= DLEAF_DIAG;
             D.inv_diag[0] = 1.0 / m[0], D.inv_diag[1] = 1.0 / m[5], D.inv_diag[2] = 1.0 / m[10];
         }
@@ -249,9 +285,9 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if (V.unit < 0 || V.unit >= lim) return fail(ctx, RTAMD_E_INVALID, "visit unit out of range");
         if (V.class_material < 0 || V.class_material >= s->n_materials) return fail(ctx, RTAMD_E_INVALID, "visit material out of range");
     }
-    // ---- device copies
+    // ---- device copies (the scene uploaded before stays in place until all of them exist)
     HIPCHK(ctx, hipDeviceSynchronize());
-    free_scene(ctx);
+    UploadGuard guard(ctx);
     DScene d{};
     d.cam = s->camera;
     d.max_remaining = s->max_remaining, d.n_lights = s->n_lights, d.n_visits = s->n_visits, d.n_leaves = s->n_leaves;
@@ -279,6 +315,8 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         const rtamd_leaf& L = s->leaves[i];
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         // object -> world: inverse of the affine world -> object matrix (bounds only: rounding is covered by the padding)
+        if (V.eq_class < 0 || V.eq_class >= std::max(s->n_classes, 1) || V.eq_class >= (1 << 23))
+            return fail(ctx, RTAMD_E_INVALID, "visit class out of range");
         const double* m = L.w2o;
         const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
         bool finite = std::isfinite(det) && det != 0.0;
@@ -551,8 +589,6 @@ int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         const rtamd_visit& V = s->visits[i];
         DVisit& D = dv[i];
         std::memset(&D, 0, sizeof D);
-        if (V.eq_class < 0 || V.eq_class >= std::max(s->n_classes, 1) || V.eq_class >= (1 << 23))
-            return fail(ctx, RTAMD_E_INVALID, "visit class out of range");
         class_mat[V.eq_class] = V.class_material;
         D.unit = V.unit;
         D.vflags_class = (V.flags & 0xffu) | ((uint32_t)V.eq_class << 8);
@@ -797,6 +833,10 @@ static int64_t part_rows(int vsize, const rtamd_rows* r) {
     return rows;
 }
 
+    guard.done = true;
+    // counters of the scene before mean nothing for this one (an overflow of its CSG lists least of all)
+    HIPCHK(ctx, hipMemset(ctx->d_stats, 0, (size_t)ctx->stat_blocks * RTAMD_STAT_STRIDE * sizeof(unsigned long long)));
+    ctx->ovf_seen = 0;
 int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows) {
     if (!ctx || !ctx->have_scene) return -1;
     return part_rows(ctx->ds.cam.vsize, rows);
@@ -933,8 +973,11 @@ int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
     }
     if (rc == RTAMD_OK) {
         rtamd_stats st;
-        if (ctx->has_csg && rtamd_get_stats(ctx, &st) == RTAMD_OK && st.csg_overflows)
-            rc = fail(ctx, RTAMD_E_OVERFLOW, "a per-lane CSG intersection list overflowed (RTAMD_CSG_LIST_CAP)");
+        if (ctx->has_csg && rtamd_get_stats(ctx, &st) == RTAMD_OK) {
+            if (st.csg_overflows > ctx->ovf_seen)
+                rc = fail(ctx, RTAMD_E_OVERFLOW, "a per-lane CSG intersection list overflowed (RTAMD_CSG_LIST_CAP)");
+            ctx->ovf_seen = st.csg_overflows;
+        }
     }
     return rc;
 }
@@ -955,9 +998,14 @@ int rtamd_color_at(rtamd_ctx* ctx, int mode, const double* h_rays, int64_t n, in
     if (n == 0) return RTAMD_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     double *d_rays = nullptr, *d_rgb = nullptr;
-    HIPCHK(ctx, hipMalloc(&d_rays, (size_t)n * 6 * sizeof(double)));
-    HIPCHK(ctx, hipMalloc(&d_rgb, (size_t)n * 3 * sizeof(double)));
-    HIPCHK(ctx, hipMemcpy(d_rays, h_rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice));
+    hipError_t e0 = hipMalloc(&d_rays, (size_t)n * 6 * sizeof(double));
+    if (e0 == hipSuccess) e0 = hipMalloc(&d_rgb, (size_t)n * 3 * sizeof(double));
+    if (e0 == hipSuccess) e0 = hipMemcpy(d_rays, h_rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
+    if (e0 != hipSuccess) {
+        if (d_rays) (void)hipFree(d_rays);
+        if (d_rgb) (void)hipFree(d_rgb);
+        return fail(ctx, RTAMD_E_HIP, std::string("color_at: ") + hipGetErrorString(e0));
+    }
     DWork w{};
     w.hsize = ctx->ds.cam.hsize, w.vsize = ctx->ds.cam.vsize;
     w.tile_rows = 1, w.part = 0, w.n_parts = 1, w.span = 1;
@@ -993,6 +1041,8 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
         for (int k = 0; k < ST_COUNT; k++) h[k] += slots[(size_t)b * RTAMD_STAT_STRIDE + k];
     out->primary_rays = h[ST_PRIMARY], out->shadow_rays = h[ST_SHADOW_RAYS], out->reflect_rays = h[ST_REFLECT];
     out->refract_rays = h[ST_REFRACT], out->container_passes = h[ST_CONTAINER];
+        // the counter is cumulative (rtamd_reset_stats, rtamd_scene_upload clear it): only what has been added
+        // since the last look is this frame's -- or that of a rtamd_render_rows call since then
     out->rays = h[ST_PRIMARY] + h[ST_SHADOW_RAYS] + h[ST_REFLECT] + h[ST_REFRACT] + h[ST_CONTAINER];
     out->shade_points = h[ST_SHADE_POINTS], out->light_samples = h[ST_LIGHT_SAMPLES], out->csg_overflows = h[ST_CSG_OVERFLOW];
     if (getenv("RTAMD_PROFILE_DUMP")) {  // diagnostic builds (-DRTAMD_PROFILE) only
@@ -1021,3 +1071,4 @@ int rtamd_reset_stats(rtamd_ctx* ctx) {
     return RTAMD_OK;
 }
 
+    ctx->ovf_seen = 0;
