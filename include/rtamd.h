@@ -200,6 +200,20 @@ int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows);
  * device the first time a partition of the frame is used (it builds the work-queue order for it). */
 int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream);
 
+/* No counterpart in the reference.  rtamd_render_rows for callers that cannot allocate device memory or wait for the
+ * device: code under HIP graph capture, serving loops, harnesses that forbid hipMalloc.  Same arguments, same pixels
+ * to the bit.  The work-queue counters and the per-lane stacks of shade-point frames live in a file-scope device
+ * array of RTAMD_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends; the call
+ * makes no hipMalloc / hipFree and no blocking copy (it also leaves out the table that puts costly pixels first in
+ * the work queue: the order of work differs, the results do not).  Limit: the frame stacks of at least one block per
+ * CU (or of the whole grid, if smaller) must fit -- recursion budget x 8 doubles (fast) or 22 doubles (strict) x 256
+ * lanes per block in 64 MiB, i.e. any budget in fast arithmetic, up to 5 in strict; beyond that RTAMD_E_LIMIT with
+ * the figures in rtamd_last_error.  With fewer blocks than rtamd_render_rows would launch (strict, budget 2..5) it is
+ * slower.  All contexts of one GPU share the array: calls that overlap on one GPU race (and so do a call of this and a
+ * call of rtamd_render_rows on the same context, which share its counters and timing events). */
+#define RTAMD_STATIC_SCRATCH_BYTES (((size_t)64 << 20) + 8192)
+int rtamd_render_rows_static(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream);
+
 /* Camera::render for the whole frame into host memory (either pointer may be NULL). Blocking.
  * The device-side frame is kept by the context between calls; the copy back runs at the rate of the
  * PCIe link when the destination came from rtamd_host_alloc, and through the driver's staging otherwise. */

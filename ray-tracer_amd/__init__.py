@@ -63,7 +63,7 @@ class Rows(C.Structure):
 
 # every symbol include/rtamd.h declares
 GPU_SYMBOLS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error", "rtamd_scene_upload", "rtamd_part_rows",
-               "rtamd_render_rows", "rtamd_render", "rtamd_host_alloc", "rtamd_host_free", "rtamd_color_at", "rtamd_get_stats",
+               "rtamd_render_rows", "rtamd_render_rows_static", "rtamd_render", "rtamd_host_alloc", "rtamd_host_free", "rtamd_color_at", "rtamd_get_stats",
                "rtamd_reset_stats"]
 
 _gpu.rtamd_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -78,6 +78,8 @@ _gpu.rtamd_part_rows.argtypes = [C.c_void_p, C.POINTER(Rows)]
 _gpu.rtamd_part_rows.restype = C.c_int64
 _gpu.rtamd_render_rows.argtypes = [C.c_void_p, C.POINTER(Rows), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 _gpu.rtamd_render_rows.restype = C.c_int
+_gpu.rtamd_render_rows_static.argtypes = _gpu.rtamd_render_rows.argtypes
+_gpu.rtamd_render_rows_static.restype = C.c_int
 _gpu.rtamd_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
 _gpu.rtamd_render.restype = C.c_int
 _gpu.rtamd_host_alloc.argtypes = [C.c_size_t]
@@ -242,12 +244,13 @@ class Context:
         r = Rows(tile_rows, part, n_parts, span)
         return _gpu.rtamd_part_rows(self._h, C.byref(r))
 
-    def render_rows(self, tile_rows, part, n_parts, mode, d_rgb=0, d_rgb8=0, stream=0, span=1):
+    def render_rows(self, tile_rows, part, n_parts, mode, d_rgb=0, d_rgb8=0, stream=0, span=1, static=False):
         """Asynchronous; d_rgb / d_rgb8 are device addresses (e.g. ``tensor.data_ptr()``).  Renders the tiles of
-        parts ``part .. part + span - 1`` of ``n_parts``."""
+        parts ``part .. part + span - 1`` of ``n_parts``.  ``static``: through rtamd_render_rows_static, the entry
+        point that allocates nothing."""
         r = Rows(tile_rows, part, n_parts, span)
-        self._chk(_gpu.rtamd_render_rows(self._h, C.byref(r), mode, C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None),
-                                         C.c_void_p(stream or None)))
+        fn = _gpu.rtamd_render_rows_static if static else _gpu.rtamd_render_rows
+        self._chk(fn(self._h, C.byref(r), mode, C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None), C.c_void_p(stream or None)))
 
     def render(self, hsize, vsize, mode=MODE_FAST, want_u8=False, pinned=False):
         """Whole frame into host arrays; (hsize, vsize) must be the resolution of the uploaded scene.

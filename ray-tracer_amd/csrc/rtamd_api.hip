@@ -60,6 +60,35 @@ struct rtamd_ctx {
 
 static std::string g_create_err;
 
+// Scratch of rtamd_render_rows_static: the work-queue counters and the per-lane stacks of shade-point frames that
+// rtamd_render_rows keeps in memory the context allocated.  One copy per GPU, held from the moment the library is
+// loaded on it until the process ends.  In host code the name below is only a handle: the address the kernels get
+// is asked for per device (static_scratch_of), with that device current.
+#define RTAMD_STATIC_QUEUE_BYTES ((size_t)RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long))
+static_assert(RTAMD_STATIC_QUEUE_BYTES + RTAMD_STATIC_FRAME_BYTES == RTAMD_STATIC_SCRATCH_BYTES, "layout of the static scratch");
+static __device__ __align__(256) unsigned char scratch[RTAMD_STATIC_SCRATCH_BYTES];
+
+#define RTAMD_MAX_DEVICES 64
+static std::mutex g_scratch_lock;
+static unsigned char* g_scratch_ptr[RTAMD_MAX_DEVICES];  // per device: where its copy of `scratch` lives
+
+// Address of the current device's copy of `scratch` (device = its index).  NULL and *err set when the runtime refuses.
+static unsigned char* static_scratch_of(int device, hipError_t* err) {
+    *err = hipSuccess;
+    if (device < 0 || device >= RTAMD_MAX_DEVICES) {
+        *err = hipErrorInvalidDevice;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        *err = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (*err != hipSuccess) return nullptr;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    return g_scratch_ptr[device];
+}
+
 #define HIPCHK(ctx, call)                                                                          \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
@@ -122,6 +151,8 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     if ((e = hipMemset(ctx->d_stats, 0, (size_t)mb * RTAMD_STAT_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    ctx->static_scratch = static_scratch_of(device, &e);  // (the device is current)
+    if (!ctx->static_scratch) return bail("hipGetSymbolAddress(scratch)", e);
     *out = ctx;
     return RTAMD_OK;
 }
@@ -173,41 +204,10 @@ static int ensure_frames(rtamd_ctx* ctx, int levels) {
     return RTAMD_OK;
 }
 
-int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
-    if (!ctx || !s) return RTAMD_E_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    // ---- validation: every index the kernel follows is checked here
-    if (s->camera.hsize <= 0 || s->camera.vsize <= 0) return fail(ctx, RTAMD_E_INVALID, "camera size must be positive");
-    if (s->max_remaining < 0 || s->max_remaining > RTAMD_MAX_REMAINING) return fail(ctx, RTAMD_E_LIMIT, "max_remaining out of range");
-    if (s->n_lights < 0 || s->n_lights > RTAMD_MAX_LIGHTS) return fail(ctx, RTAMD_E_LIMIT, "too many lights");
-    if (s->n_leaves >= (1 << (31 - RTAMD_KEY_SHIFT))) return fail(ctx, RTAMD_E_LIMIT, "too many leaves");
-    if (s->n_leaves < 0 || s->n_chain < 0 || s->n_tris < 0 || s->n_materials < 0 || s->n_csg_nodes < 0 || s->n_csg_roots < 0 ||
-        s->n_visits < 0 || s->n_classes < 0)
-        return fail(ctx, RTAMD_E_INVALID, "negative count");
-    if ((s->n_lights && !s->lights) || (s->n_leaves && !s->leaves) || (s->n_chain && !s->chain) ||
-        (s->n_tris && (!s->tri_geom || !s->tri_normals)) || (s->n_materials && !s->materials) ||
-        (s->n_csg_nodes && !s->csg_nodes) || (s->n_csg_roots && !s->csg_roots) || (s->n_visits && !s->visits))
-        return fail(ctx, RTAMD_E_INVALID, "NULL array with a non-zero count");
-    std::vector<DLeaf> dl((size_t)s->n_leaves);
-    long long order = 0;
-    for (int i = 0; i < s->n_leaves; i++) {
-        const rtamd_leaf& L = s->leaves[i];
-        if (L.kind < RTAMD_SPHERE || L.kind > RTAMD_MESH) return fail(ctx, RTAMD_E_INVALID, "leaf kind out of range");
-        if (L.material < 0 || L.material >= s->n_materials) return fail(ctx, RTAMD_E_INVALID, "leaf material index out of range");
-        if (L.chain_len < 1 || L.chain_len > RTAMD_MAX_CHAIN || L.chain_start < 0 || L.chain_start + L.chain_len > s->n_chain)
-            return fail(ctx, RTAMD_E_INVALID, "leaf transform chain out of range");
-        if (L.eq_class < 0 || L.eq_class >= std::max(s->n_classes, 1)) return fail(ctx, RTAMD_E_INVALID, "leaf class out of range");
-        int slots = 0;
-        if (L.kind == RTAMD_MESH) {
-            if (L.tri_count > RTAMD_MAX_MESH_TRIS) return fail(ctx, RTAMD_E_LIMIT, "mesh leaf with more than RTAMD_MAX_MESH_TRIS triangles");
-            if (L.tri_count < 1 || L.tri_start < 0 || (long long)L.tri_start + L.tri_count > s->n_tris)
-                return fail(ctx, RTAMD_E_INVALID, "mesh triangle range out of range");
-            slots = L.tri_count;
-        } else {
 static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s);
 
-            slots = 4;
-        }
+int rtamd_scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
+    if (!ctx || !s) return RTAMD_E_INVALID;
     try {  // the host-side tables below are std::vectors: nothing may unwind across the C boundary
         return scene_upload(ctx, s);
     } catch (const std::bad_alloc&) {
@@ -237,6 +237,38 @@ struct UploadGuard {
 }  // namespace
 
 static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // ---- validation: every index the kernel follows is checked here
+    if (s->camera.hsize <= 0 || s->camera.vsize <= 0) return fail(ctx, RTAMD_E_INVALID, "camera size must be positive");
+    if (s->max_remaining < 0 || s->max_remaining > RTAMD_MAX_REMAINING) return fail(ctx, RTAMD_E_LIMIT, "max_remaining out of range");
+    if (s->n_lights < 0 || s->n_lights > RTAMD_MAX_LIGHTS) return fail(ctx, RTAMD_E_LIMIT, "too many lights");
+    if (s->n_leaves >= (1 << (31 - RTAMD_KEY_SHIFT))) return fail(ctx, RTAMD_E_LIMIT, "too many leaves");
+    if (s->n_leaves < 0 || s->n_chain < 0 || s->n_tris < 0 || s->n_materials < 0 || s->n_csg_nodes < 0 || s->n_csg_roots < 0 ||
+        s->n_visits < 0 || s->n_classes < 0)
+        return fail(ctx, RTAMD_E_INVALID, "negative count");
+    if (s->n_classes > std::max(s->n_leaves, 1)) return fail(ctx, RTAMD_E_INVALID, "more equality classes than leaves");
+    if ((s->n_lights && !s->lights) || (s->n_leaves && !s->leaves) || (s->n_chain && !s->chain) ||
+        (s->n_tris && (!s->tri_geom || !s->tri_normals)) || (s->n_materials && !s->materials) ||
+        (s->n_csg_nodes && !s->csg_nodes) || (s->n_csg_roots && !s->csg_roots) || (s->n_visits && !s->visits))
+        return fail(ctx, RTAMD_E_INVALID, "NULL array with a non-zero count");
+    std::vector<DLeaf> dl((size_t)s->n_leaves);
+    long long order = 0;
+    for (int i = 0; i < s->n_leaves; i++) {
+        const rtamd_leaf& L = s->leaves[i];
+        if (L.kind < RTAMD_SPHERE || L.kind > RTAMD_MESH) return fail(ctx, RTAMD_E_INVALID, "leaf kind out of range");
+        if (L.material < 0 || L.material >= s->n_materials) return fail(ctx, RTAMD_E_INVALID, "leaf material index out of range");
+        if (L.chain_len < 1 || L.chain_len > RTAMD_MAX_CHAIN || L.chain_start < 0 || L.chain_start + L.chain_len > s->n_chain)
+            return fail(ctx, RTAMD_E_INVALID, "leaf transform chain out of range");
+        if (L.eq_class < 0 || L.eq_class >= std::max(s->n_classes, 1)) return fail(ctx, RTAMD_E_INVALID, "leaf class out of range");
+        int slots = 0;
+        if (L.kind == RTAMD_MESH) {
+            if (L.tri_count > RTAMD_MAX_MESH_TRIS) return fail(ctx, RTAMD_E_LIMIT, "mesh leaf with more than RTAMD_MAX_MESH_TRIS triangles");
+            if (L.tri_count < 1 || L.tri_start < 0 || (long long)L.tri_start + L.tri_count > s->n_tris)
+                return fail(ctx, RTAMD_E_INVALID, "mesh triangle range out of range");
+            slots = L.tri_count;
+        } else {
+            slots = 4;
+        }
         DLeaf& D = dl[i];
         std::memset(&D, 0, sizeof D);
         std::memcpy(D.w2o, L.w2o, sizeof L.w2o);
@@ -246,7 +278,6 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         const double* m = L.w2o;
         if (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0 && m[0] != 0.0 && m[5] != 0.0 &&
             m[10] != 0.0) {
-    if (s->n_classes > std::max(s->n_leaves, 1)) return fail(ctx, RTAMD_E_INVALID, "more equality classes than leaves");
             D.flags |= DLEAF_DIAG;
             D.inv_diag[0] = 1.0 / m[0], D.inv_diag[1] = 1.0 / m[5], D.inv_diag[2] = 1.0 / m[10];
         }
@@ -284,6 +315,8 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         int lim = (V.flags & RTAMD_VISIT_CSG) ? s->n_csg_roots : s->n_leaves;
         if (V.unit < 0 || V.unit >= lim) return fail(ctx, RTAMD_E_INVALID, "visit unit out of range");
         if (V.class_material < 0 || V.class_material >= s->n_materials) return fail(ctx, RTAMD_E_INVALID, "visit material out of range");
+        if (V.eq_class < 0 || V.eq_class >= std::max(s->n_classes, 1) || V.eq_class >= (1 << 23))
+            return fail(ctx, RTAMD_E_INVALID, "visit class out of range");
     }
     // ---- device copies (the scene uploaded before stays in place until all of them exist)
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -315,8 +348,6 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         const rtamd_leaf& L = s->leaves[i];
         double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         // object -> world: inverse of the affine world -> object matrix (bounds only: rounding is covered by the padding)
-        if (V.eq_class < 0 || V.eq_class >= std::max(s->n_classes, 1) || V.eq_class >= (1 << 23))
-            return fail(ctx, RTAMD_E_INVALID, "visit class out of range");
         const double* m = L.w2o;
         const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
         bool finite = std::isfinite(det) && det != 0.0;
@@ -802,6 +833,10 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if (has_bounds) ctx->variant |= 16;
     }
     ctx->have_scene = true;
+    guard.done = true;
+    // counters of the scene before mean nothing for this one (an overflow of its CSG lists least of all)
+    HIPCHK(ctx, hipMemset(ctx->d_stats, 0, (size_t)ctx->stat_blocks * RTAMD_STAT_STRIDE * sizeof(unsigned long long)));
+    ctx->ovf_seen = 0;
     return RTAMD_OK;
 }
 
@@ -833,25 +868,41 @@ static int64_t part_rows(int vsize, const rtamd_rows* r) {
     return rows;
 }
 
-    guard.done = true;
-    // counters of the scene before mean nothing for this one (an overflow of its CSG lists least of all)
-    HIPCHK(ctx, hipMemset(ctx->d_stats, 0, (size_t)ctx->stat_blocks * RTAMD_STAT_STRIDE * sizeof(unsigned long long)));
-    ctx->ovf_seen = 0;
 int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows) {
     if (!ctx || !ctx->have_scene) return -1;
     return part_rows(ctx->ds.cam.vsize, rows);
 }
 
-static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
+// static_scratch: the work-queue counters and the frame stacks live in this device's copy of the file-scope `scratch`
+// array instead of the context's own buffers, and nothing on the way allocates, frees or waits for the device.
+static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool static_scratch = false) {
     if (mode != RTAMD_MODE_STRICT && mode != RTAMD_MODE_FAST) return fail(ctx, RTAMD_E_INVALID, "unknown mode");
-    int rc = ensure_frames(ctx, std::max(1, w.remaining));
-    if (rc) return rc;
-    w.queue_head = ctx->d_queue;
-    w.stats = ctx->d_stats;
-    w.frames = ctx->d_frames;
-    w.total_lanes = ctx->total_lanes;
     int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->variant], (w.n_pixels + 255) / 256);
     blocks = std::max(blocks, 1);
+    w.stats = ctx->d_stats;
+    if (static_scratch) {
+        // The frame stacks of one block: levels x doubles per frame x 256 lanes.  The grid is cut down to what the
+        // array holds; below one block per CU the call is refused instead of crawling.
+        const int64_t levels = std::max(1, w.remaining);
+        const int64_t per_block = levels * (mode == RTAMD_MODE_STRICT ? RTAMD_FRAME_F64_STRICT : RTAMD_FRAME_F64_FAST) * 256 * (int64_t)sizeof(double);
+        const int64_t fit = (int64_t)RTAMD_STATIC_FRAME_BYTES / per_block;
+        if (fit < std::min<int64_t>(ctx->num_cus, blocks))
+            return fail(ctx, RTAMD_E_LIMIT,
+                        "rtamd_render_rows_static: the frame stacks for recursion budget " + std::to_string(w.remaining) + " in " +
+                            (mode == RTAMD_MODE_STRICT ? "strict" : "fast") + " arithmetic need " + std::to_string(per_block) +
+                            " bytes per block; fewer than one block per CU fit the static scratch of " +
+                            std::to_string((long long)RTAMD_STATIC_FRAME_BYTES) + " bytes (use rtamd_render_rows)");
+        blocks = (int)std::min<int64_t>(blocks, fit);
+        w.queue_head = reinterpret_cast<unsigned long long*>(ctx->static_scratch);
+        w.frames = reinterpret_cast<double*>(ctx->static_scratch + RTAMD_STATIC_QUEUE_BYTES);
+        w.total_lanes = (int64_t)blocks * 256;
+    } else {
+        int rc = ensure_frames(ctx, std::max(1, w.remaining));
+        if (rc) return rc;
+        w.queue_head = ctx->d_queue;
+        w.frames = ctx->d_frames;
+        w.total_lanes = ctx->total_lanes;
+    }
     // Camera rays: blocks of RTAMD_BLOCK_W x RTAMD_BLOCK_H pixels when the row tiles are whole multiples of the block height (no block then straddles
     // two tiles, which lie far apart in the frame); strips of 64 pixels otherwise and for caller-supplied rays.
     w.gcols = 0, w.n_rows = 0;
@@ -871,7 +922,9 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     if (const char* e = getenv("RTAMD_REFILL_MIN")) w.refill_min = atoi(e);  // diagnostic
     w.mesh_few = 32;
     if (const char* e = getenv("RTAMD_MESH_FEW")) w.mesh_few = atoi(e);  // diagnostic: 0 = always the loop, 64 = never
-    if (!w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
+    // (the table is memory the context allocates and fills with a blocking copy: not for static_scratch, whose
+    // pixels are the same bits in another order of work)
+    if (!static_scratch && !w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
         // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
         // The table depends on the partition of the frame only: it is kept until that changes.
         const std::array<int64_t, 6> key{{w.hsize, w.vsize, w.tile_rows, w.part, w.n_parts, w.span}};
@@ -915,7 +968,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
         }
         if (ctx->order_used) w.order = ctx->d_order;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_queue, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
+    HIPCHK(ctx, hipMemsetAsync(w.queue_head, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, ctx->variant, blocks, stream)
                                              : rtamd_launch_fast(ctx->ds, w, ctx->variant, blocks, stream);
@@ -925,7 +978,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream) {
     return RTAMD_OK;
 }
 
-int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream) {
+static int render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream, bool static_scratch) {
     if (!ctx) return RTAMD_E_INVALID;
     if (!ctx->have_scene) return fail(ctx, RTAMD_E_NO_SCENE, "no scene uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -939,7 +992,15 @@ int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* 
     w.n_pixels = nrows * ctx->ds.cam.hsize;
     w.custom_rays = nullptr;
     w.out_rgb = d_rgb, w.out_rgb8 = d_rgb8;
-    return launch(ctx, mode, w, (hipStream_t)stream);
+    return launch(ctx, mode, w, (hipStream_t)stream, static_scratch);
+}
+
+int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream) {
+    return render_rows(ctx, rows, mode, d_rgb, d_rgb8, stream, false);
+}
+
+int rtamd_render_rows_static(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream) {
+    return render_rows(ctx, rows, mode, d_rgb, d_rgb8, stream, true);
 }
 
 int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
@@ -972,6 +1033,8 @@ int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
         if (e != hipSuccess) rc = fail(ctx, RTAMD_E_HIP, std::string("render: ") + hipGetErrorString(e));
     }
     if (rc == RTAMD_OK) {
+        // the counter is cumulative (rtamd_reset_stats, rtamd_scene_upload clear it): only what has been added
+        // since the last look is this frame's -- or that of a rtamd_render_rows call since then
         rtamd_stats st;
         if (ctx->has_csg && rtamd_get_stats(ctx, &st) == RTAMD_OK) {
             if (st.csg_overflows > ctx->ovf_seen)
@@ -1041,8 +1104,6 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
         for (int k = 0; k < ST_COUNT; k++) h[k] += slots[(size_t)b * RTAMD_STAT_STRIDE + k];
     out->primary_rays = h[ST_PRIMARY], out->shadow_rays = h[ST_SHADOW_RAYS], out->reflect_rays = h[ST_REFLECT];
     out->refract_rays = h[ST_REFRACT], out->container_passes = h[ST_CONTAINER];
-        // the counter is cumulative (rtamd_reset_stats, rtamd_scene_upload clear it): only what has been added
-        // since the last look is this frame's -- or that of a rtamd_render_rows call since then
     out->rays = h[ST_PRIMARY] + h[ST_SHADOW_RAYS] + h[ST_REFLECT] + h[ST_REFRACT] + h[ST_CONTAINER];
     out->shade_points = h[ST_SHADE_POINTS], out->light_samples = h[ST_LIGHT_SAMPLES], out->csg_overflows = h[ST_CSG_OVERFLOW];
     if (getenv("RTAMD_PROFILE_DUMP")) {  // diagnostic builds (-DRTAMD_PROFILE) only
@@ -1068,7 +1129,7 @@ int rtamd_reset_stats(rtamd_ctx* ctx) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, hipMemset(ctx->d_stats, 0, (size_t)ctx->stat_blocks * RTAMD_STAT_STRIDE * sizeof(unsigned long long)));
+    ctx->ovf_seen = 0;
     return RTAMD_OK;
 }
 
-    ctx->ovf_seen = 0;

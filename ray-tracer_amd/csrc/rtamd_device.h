@@ -102,7 +102,10 @@ enum {
 #define RTAMD_BLOCK_H (64 / RTAMD_BLOCK_W)
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
 #define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
-#define RTAMD_FRAME_F64 22   // doubles per saved shade-point frame
+#define RTAMD_FRAME_F64_STRICT 22  // doubles per saved shade-point frame: STRICT keeps the whole shade point,
+#define RTAMD_FRAME_F64_FAST 8     // FAST the refraction ray it still owes (origin, direction, weight, budget)
+#define RTAMD_FRAME_F64 RTAMD_FRAME_F64_STRICT  // what the context's own buffer is sized for
+#define RTAMD_STATIC_FRAME_BYTES ((size_t)64 << 20)  // frame stacks inside the static scratch of rtamd_render_rows_static
 #define RTAMD_QUEUES 64        // counters the work queue is split into
 #define RTAMD_QUEUE_STRIDE 16  // 64-bit words between two counters (128 bytes)
 

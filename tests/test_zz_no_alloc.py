@@ -1,0 +1,70 @@
+"""rtamd_render_rows_static -- the entry point that allocates nothing -- against rtamd_render_rows, through the C ABI.
+
+The two share the kernels; what differs is where the work-queue counters and the per-lane frame stacks live (a
+file-scope device array of the library instead of buffers of the context) and the order in which the groups of
+pixels are handed out.  Neither may change a bit of the frame: integer-exact equality of the f64 pixels and of
+the 8-bit channels is the bar, in both arithmetic modes, on two calls in a row of which the second is smaller
+(the array keeps the first call's contents)."""
+import numpy as np
+import pytest
+
+from conftest import sg_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(rt, ctx, w, rows_spec, mode, static):
+    import torch
+    tile_rows, part, n_parts, span = rows_spec
+    n = ctx.part_rows(tile_rows, part, n_parts, span)
+    buf = torch.full((n, w, 3), float("nan"), dtype=torch.float64, device="cuda")
+    buf8 = torch.full((n, w, 3), 77, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx.render_rows(tile_rows, part, n_parts, mode, d_rgb=buf.data_ptr(), d_rgb8=buf8.data_ptr(), stream=stream, span=span, static=static)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    return buf.cpu().numpy(), buf8.cpu().numpy(), free0 - free1
+
+
+@pytest.mark.parametrize("name", ["cover", "teapot_lowres_room", "csg"])
+def test_static_entry_point_gives_the_bits_of_render_rows(rt, gpu_ctx, name):
+    # first a whole frame, then a smaller input: fewer rows (one of three interleaved parts), then a smaller scene
+    for (w, h), spec in (((200, 120), (120, 0, 1, 1)), ((200, 120), (8, 1, 3, 1)), ((72, 40), (40, 0, 1, 1))):
+        gpu_ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(w, h).flatten())
+        for mode in (rt.MODE_FAST, rt.MODE_STRICT):
+            want, want8, _ = _rows(rt, gpu_ctx, w, spec, mode, static=False)
+            gpu_ctx.reset_stats()
+            got, got8, grew = _rows(rt, gpu_ctx, w, spec, mode, static=True)
+            st = gpu_ctx.stats()
+            assert np.isfinite(got).all()
+            assert np.array_equal(got, want) and np.array_equal(got8, want8), (name, w, h, spec, mode)
+            assert st.primary_rays == got.shape[0] * w and st.csg_overflows == 0
+            assert grew == 0  # no device memory was taken during the call
+
+
+def test_static_entry_point_shared_by_contexts_and_limits(rt, gpu_ctx):
+    """All contexts of a GPU share the one array (calls one after the other are fine); a recursion budget whose frame
+    stacks do not fit is refused with RTAMD_E_LIMIT and a message, and the context stays usable."""
+    abi = __import__("importlib").import_module("ray-tracer_amd.abi")
+    w, h = 320, 240
+    other = rt.Context(0)
+    other.upload(rt.Scene.from_sg(sg_path("glass_spheres")).set_resolution(w, h).flatten())
+    gpu_ctx.upload(rt.Scene.from_sg(sg_path("tables")).set_resolution(w, h).flatten())
+    a, _, _ = _rows(rt, other, w, (h, 0, 1, 1), rt.MODE_FAST, static=True)
+    b, _, _ = _rows(rt, gpu_ctx, w, (h, 0, 1, 1), rt.MODE_FAST, static=True)
+    a2, _, _ = _rows(rt, other, w, (h, 0, 1, 1), rt.MODE_FAST, static=False)
+    b2, _, _ = _rows(rt, gpu_ctx, w, (h, 0, 1, 1), rt.MODE_FAST, static=False)
+    assert np.array_equal(a, a2) and np.array_equal(b, b2)
+    # budget 8: 8 x 22 doubles x 256 lanes = 352 KiB per block in strict arithmetic, 186 blocks in 64 MiB < 256 CUs
+    other.upload(rt.Scene.from_sg(sg_path("glass_spheres")).set_resolution(w, h).flatten(8))
+    with pytest.raises(rt.RtamdError, match=str(abi.E_LIMIT)) as e:
+        _rows(rt, other, w, (h, 0, 1, 1), rt.MODE_STRICT, static=True)
+    assert "static scratch" in str(e.value)
+    deep, _, _ = _rows(rt, other, w, (h, 0, 1, 1), rt.MODE_FAST, static=True)  # fast arithmetic: 8 doubles per frame, fits
+    deep2, _, _ = _rows(rt, other, w, (h, 0, 1, 1), rt.MODE_FAST, static=False)
+    assert np.array_equal(deep, deep2)
+    strict, _, _ = _rows(rt, other, w, (h, 0, 1, 1), rt.MODE_STRICT, static=False)  # the allocating entry point takes it
+    assert np.abs(strict - deep).max() <= 1e-8
+    other.close()
