@@ -1042,4 +1042,43 @@ int orc_color_at(void* s, int mode, const double* rays, int64_t n, int remaining
     return rc;
 }
 
+// Diagnostic for tests: the first hit of one ray as Intersection::prepare_computations (src/intersection.rs:70-128)
+// describes it.  out = t, point xyz, over_point xyz, normalv xyz, reflectv xyz, inside (0/1), kind of the shape hit,
+// whether each light is shadowed at over_point (bit k of out[15] as a double) -- 16 doubles.  Returns 1 hit, 0 miss, -1 error.
+int orc_first_hit(void* s, const double* ray, double* out) {
+    auto* sc = (orc::Scene*)s;
+    orc::world_refresh_parents(sc->world);
+    orc::Ctx c;
+    void* cache = orc::new_thread_cache();
+    orc::set_thread_cache(cache);
+    int rc = 0;
+    try {
+        orc::Ray r{orc::pt(ray[0], ray[1], ray[2]), orc::vec(ray[3], ray[4], ray[5])};
+        orc::Xs xs = orc::world_intersect(c, sc->world, r);
+        const orc::Intersection* h = orc::hit(xs);
+        if (h) {
+            orc::Intersection i = *h;
+            orc::Comps k = orc::prepare_computations(c, i, r, xs);
+            out[0] = k.t;
+            out[1] = k.point.x, out[2] = k.point.y, out[3] = k.point.z;
+            out[4] = k.over_point.x, out[5] = k.over_point.y, out[6] = k.over_point.z;
+            out[7] = k.normalv.x, out[8] = k.normalv.y, out[9] = k.normalv.z;
+            out[10] = k.reflectv.x, out[11] = k.reflectv.y, out[12] = k.reflectv.z;
+            out[13] = k.inside ? 1.0 : 0.0;
+            out[14] = (double)k.object->kind;
+            unsigned bits = 0;
+            for (size_t l = 0; l < sc->world.lights.size() && l < 32; l++)
+                if (orc::is_shadowed(c, sc->world, sc->world.lights[l], k.over_point)) bits |= 1u << l;
+            out[15] = (double)bits;
+            rc = 1;
+        }
+    } catch (std::exception& e) {
+        g_err = e.what();
+        rc = -1;
+    }
+    orc::set_thread_cache(nullptr);
+    orc::free_thread_cache(cache);
+    return rc;
+}
+
 }  // extern "C"

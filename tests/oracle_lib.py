@@ -36,6 +36,8 @@ def lib():
         _lib.orc_render_pixels.restype = C.c_int
         _lib.orc_color_at.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         _lib.orc_color_at.restype = C.c_int
+        _lib.orc_first_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_first_hit.restype = C.c_int
     return _lib
 
 
@@ -69,6 +71,18 @@ class OracleScene:
         if lib().orc_color_at(self._h, 1 if faithful else 0, rays.ctypes.data, rays.shape[0], remaining, out.ctypes.data):
             raise RuntimeError("oracle: " + lib().orc_last_error().decode())
         return out
+
+    def first_hit(self, ray):
+        """Diagnostic: prepare_computations of the ray's hit as a dict, or None for a miss."""
+        ray = np.ascontiguousarray(ray, dtype=np.float64).reshape(6)
+        out = np.zeros(16)
+        rc = lib().orc_first_hit(self._h, ray.ctypes.data, out.ctypes.data)
+        if rc < 0:
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        if rc == 0:
+            return None
+        return dict(t=out[0], point=out[1:4].copy(), over_point=out[4:7].copy(), normalv=out[7:10].copy(), reflectv=out[10:13].copy(),
+                    inside=bool(out[13]), kind=int(out[14]), shadowed=int(out[15]))
 
     def render(self, hsize=0, vsize=0, faithful=False, threads=1):
         if hsize <= 0:
