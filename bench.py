@@ -32,6 +32,24 @@ LEAF_FLOPS = {"sphere": 33 + 29, "plane": 14, "cube": 33 + 23, "cylinder_open": 
               "cone_open": 33 + 40, "cone_closed": 33 + 63, "tri": 51}
 SHADE_POINT_FLOPS = 100
 LIGHT_SAMPLE_FLOPS = 60
+# flops of the tests the kernel executes, per lane-test counted by rtamd_stats (fma = 2): what the formulation on the
+# device costs, not what the reference's costs -- an axis-aligned cube is two world-space slabs (6 fma, min, max, min,
+# 2 compares) and, for the rays those do not reject, a third (3 fma, min, max, 4 compares); a triangle is the first half
+# of Moeller-Trumbore (cross, dot, reciprocal, sub, dot, compares) and for the survivors the second
+EXECUTED_FLOPS = {"tests_sphere": 33 + 29, "tests_plane": 14, "tests_cube": 33 + 23, "tests_slab2": 17, "tests_slab3": 12,
+                  "tests_cylinder": 33 + 34, "tests_cone": 33 + 40, "tests_caps": 21, "tests_tri_first": 30, "tests_tri_second": 21,
+                  "tests_box": 22, "tests_run_transform": 33}
+
+
+def source_stamp():
+    """Hash of the sources the render kernels are built from: a measured-traffic file is only quoted for the kernel
+    it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rtamd_kernel.inc", "rtamd_device.h", "rtamd_api.hip"):
+        with open(os.path.join(ROOT, "ray-tracer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def flops_per_ray(sg_path):
@@ -74,6 +92,9 @@ def main():
                     help="with several GPUs: 'equal', 'K0:K' (rank 0 holds K0 interleaved parts of the frame, every other rank K), "
                          "or 'auto': a few such splits are tried during warm-up and the fastest is timed -- rank 0's rows do not "
                          "travel, every other rank's cross one xGMI link")
+    ap.add_argument("--brute-force", action="store_true",
+                    help="diagnostic: no bounds records, no re-cut of triangle pools, every run of triangles tested for every ray "
+                         "(what the reference's World::intersect does), so that the algorithmic roofline fraction is a utilisation")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="with one GPU: still go through the process group, the gather and the two frames in flight of the "
                          "multi-GPU path (a rehearsal of that code on a one-GPU box; the figures are not comparable)")
@@ -101,6 +122,8 @@ def main():
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if a.brute_force:
+        os.environ["RTAMD_BRUTE_FORCE"] = "1"  # read by the library at upload and at launch
     rt = importlib.import_module("ray-tracer_amd")
     rows_mod = importlib.import_module("ray-tracer_amd.rows")
     mode = rt.MODE_FAST if a.mode == "fast" else rt.MODE_STRICT
@@ -211,39 +234,81 @@ def main():
         dist.all_reduce(phase, op=dist.ReduceOp.MAX)
     render_alone_ms, gather_ms = float(phase[0]), float(phase[1])
     rays, shade_points, light_samples, containers = [float(x) / a.steps for x in counts]
+    # One more frame (untimed) with the kernels that count the tests their traversals execute: the timed frames use
+    # the kernels without the counters, which cost 5-15 %.  Same scene, same rows, so the counts are those of a timed frame.
+    spare = torch.empty((max(fg.n_rows, 1), W, 3), dtype=torch.float64, device=dev)
+    ctx.reset_stats()
+    ctx.count_work(True)
+    ctx.render_rows(R, fg.part, fg.n_parts, mode, d_rgb=spare.data_ptr(), stream=cur.cuda_stream, span=fg.span)
+    torch.cuda.synchronize()
+    st = ctx.stats()
+    ctx.count_work(False)
+    counting_kernel_ms = st.kernel_ms
+    tests = torch.tensor([float(getattr(st, n)) for n in EXECUTED_FLOPS], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tests)
+    lane_tests = {n: float(x) for n, x in zip(EXECUTED_FLOPS, tests)}
+    # the reference's own arithmetic order, once, for the record (not the headline)
+    strict_ms = None
+    if world == 1 and not use_dist and a.mode == "fast":
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = []
+        for _ in range(3):
+            e0.record()
+            ctx.render_rows(R, fg.part, fg.n_parts, rt.MODE_STRICT, d_rgb=spare.data_ptr(), stream=cur.cuda_stream, span=fg.span)
+            e1.record()
+            torch.cuda.synchronize()
+            t.append(e0.elapsed_time(e1))
+        strict_ms = float(np.median(t))
+    del spare
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         fpr = flops_per_ray(sg)
-        flops = (rays + containers) * fpr + shade_points * SHADE_POINT_FLOPS + light_samples * LIGHT_SAMPLE_FLOPS
+        shading_flops = shade_points * SHADE_POINT_FLOPS + light_samples * LIGHT_SAMPLE_FLOPS
+        flops = rays * fpr + shading_flops  # (the n1/n2 container passes are this design's own: not algorithmic rays)
         achieved = flops / (kernel_ms * 1e-3) / 1e12  # per rank-kernel: flops of all ranks / slowest kernel
+        executed_flops = sum(lane_tests[n] * f for n, f in EXECUTED_FLOPS.items()) + shading_flops
+        executed = executed_flops / (kernel_ms * 1e-3) / 1e12
+        # HBM bytes per launch from the PMC counters: measured by scripts/collect_profiles.sh in rocprofv3 runs of their
+        # own; quoted only if that file was measured on the kernel sources of this run
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_hbm_{a.scene}_{W}x{H}_{a.mode}.json")
-        if world == 1 and not use_dist and os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        if world == 1 and not use_dist and not a.brute_force and os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec.get("source_stamp") == source_stamp():
+                traffic = rec.get("hbm_bytes_per_launch")
         out = {
             "metric": "Mrays/sec (primary+secondary) & frame time, cover.yaml 4K, 1/2/4/8 MI355X",
             "value": rays / (ms_per_step * 1e-3) / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": f"the reference's own scene ({a.scene}, committed as a scene graph under tests/golden/scenes/); no dataset, no random input",
             "config": {"workload": f"{a.scene} scene graph at {W}x{H}, recursion budget 4, {a.mode} arithmetic",
                        "rays_per_frame": rays, "pixels": W * H, "parallelism": f"rows{world}",
                        "row_tiles": f"cyclic, {R} rows" + ("" if world == 1 else f"; rank 0 holds {share[0]} of {fg.n_parts} interleaved parts, "
                                                            f"every other rank {share[1]}"),
                        **({"share_trials_ms_per_frame": trials} if trials else {}),
-                       "frames_in_flight": in_flight, **({"rehearsal": "collective path on one rank"} if use_dist and world == 1 else {})},
+                       "frames_in_flight": in_flight, **({"rehearsal": "collective path on one rank"} if use_dist and world == 1 else {}),
+                       **({"brute_force": "no bounds records, every triangle of every run tested for every ray"} if a.brute_force else {}),
+                       **({"strict_arithmetic_kernel_ms": strict_ms} if strict_ms is not None else {})},
             "phases": {"render_ms": render_alone_ms, "gather_ms": gather_ms,
                        "note": "one frame at a time outside the timed region, slowest rank: render kernel, then gather to rank 0 + de-interleave"},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": achieved / (FP64_VALU_PEAK_TFLOPS * world), "traffic": traffic,
                          "kernel_ms": kernel_ms, "flops_per_ray": fpr, "algorithmic_flops_per_frame": flops,
+                         "executed": executed, "executed_frac": executed / (FP64_VALU_PEAK_TFLOPS * world),
+                         "executed_flops_per_frame": executed_flops, "executed_lane_tests_per_frame": lane_tests,
+                         "counting_kernel_ms": counting_kernel_ms,
                          "hbm_algorithmic_bytes_per_frame": W * H * 24,
                          "hbm_frac": W * H * 24 / (kernel_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
         }
         if fpr > 100000 or achieved > FP64_VALU_PEAK_TFLOPS * world:
             # the brute-force constant counts leaf tests that the bounds records (triangles, groups of bounded leaves) skip
-            out["roofline"]["note"] = "algorithmic flops count every leaf for every ray; bounds records skip most of those tests here, so frac is not a utilisation"
+            out["roofline"]["note"] = ("algorithmic flops count every leaf for every ray; bounds records skip most of those tests here, so frac "
+                                       "is not a utilisation: executed_frac (flops of the tests the kernel counted) is, and --brute-force gives the "
+                                       "algorithmic figure with nothing skipped")
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"], out["parity"] = cpu_baseline(a, sg, frame, rt)
         print(json.dumps(out), flush=True)

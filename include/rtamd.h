@@ -171,6 +171,19 @@ typedef struct rtamd_stats {
     uint64_t light_samples; /* lighting() evaluations */
     uint64_t csg_overflows; /* lanes whose CSG list overflowed (results then invalid) */
     double kernel_ms;       /* duration of the last render kernel, from HIP events on its stream */
+    /* Work the traversals executed, in lane-tests: one ray against one leaf, box or triangle.  The reference tests
+     * every leaf for every ray (src/scene.rs:19-26); the device passes over leaves no ray of a wave can meet, so these
+     * are what an achieved-throughput figure has to be built from. */
+    uint64_t tests_sphere, tests_plane;
+    uint64_t tests_cube;       /* the reference's slab formula, src/shapes/cube.rs:31-66 */
+    uint64_t tests_slab2;      /* axis-aligned cube as a world-space box (fast arithmetic): first two slabs */
+    uint64_t tests_slab3;      /* ... third slab + hit bookkeeping, only for rays the first two did not reject */
+    uint64_t tests_cylinder, tests_cone;
+    uint64_t tests_caps;       /* end caps of closed cylinders / cones */
+    uint64_t tests_tri_first;  /* Moeller-Trumbore up to u (src/shapes/triangle.rs:57-68) */
+    uint64_t tests_tri_second; /* ... v and t (:69-80), only for rays the first half did not reject */
+    uint64_t tests_box;        /* bounds of leaf groups, triangle runs, CSG objects (no counterpart in the reference) */
+    uint64_t tests_run_transform; /* Ray::transform into the space of a run of triangles (src/ray.rs:18-23) */
 } rtamd_stats;
 
 typedef struct rtamd_ctx rtamd_ctx;
@@ -227,6 +240,11 @@ void rtamd_host_free(void* p);
 /* World::color_at(ray, remaining) (src/scene.rs:53-63) for n caller-supplied rays:
  * h_rays = n x 6 doubles (origin xyz, direction xyz), h_rgb = n x 3 doubles. Blocking. */
 int rtamd_color_at(rtamd_ctx* ctx, int mode, const double* h_rays, int64_t n, int remaining, double* h_rgb);
+
+/* No counterpart in the reference.  on != 0: the renders of this context that follow use kernels that also count the
+ * tests their traversals execute (the tests_* fields of rtamd_stats; they stay zero otherwise).  Same pixels; the
+ * counting costs 5-15 % of a frame, which is why it is a choice. */
+int rtamd_count_work(rtamd_ctx* ctx, int on);
 
 /* Counters accumulated since the last reset (waits for the stream of the last render). */
 int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out);

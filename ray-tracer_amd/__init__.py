@@ -51,7 +51,10 @@ _host = _load("librtamd_host.so")
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "primary_rays", "shadow_rays", "reflect_rays", "refract_rays",
                                           "container_passes", "shade_points", "light_samples", "csg_overflows")] + \
-               [("kernel_ms", C.c_double)]
+               [("kernel_ms", C.c_double)] + \
+               [(n, C.c_uint64) for n in ("tests_sphere", "tests_plane", "tests_cube", "tests_slab2", "tests_slab3", "tests_cylinder",
+                                          "tests_cone", "tests_caps", "tests_tri_first", "tests_tri_second", "tests_box",
+                                          "tests_run_transform")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -64,7 +67,7 @@ class Rows(C.Structure):
 # every symbol include/rtamd.h declares
 GPU_SYMBOLS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error", "rtamd_scene_upload", "rtamd_part_rows",
                "rtamd_render_rows", "rtamd_render_rows_static", "rtamd_render", "rtamd_host_alloc", "rtamd_host_free", "rtamd_color_at", "rtamd_get_stats",
-               "rtamd_reset_stats"]
+               "rtamd_reset_stats", "rtamd_count_work"]
 
 _gpu.rtamd_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
 _gpu.rtamd_ctx_create.restype = C.c_int
@@ -92,6 +95,8 @@ _gpu.rtamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
 _gpu.rtamd_get_stats.restype = C.c_int
 _gpu.rtamd_reset_stats.argtypes = [C.c_void_p]
 _gpu.rtamd_reset_stats.restype = C.c_int
+_gpu.rtamd_count_work.argtypes = [C.c_void_p, C.c_int]
+_gpu.rtamd_count_work.restype = C.c_int
 
 _host.rth_last_error.restype = C.c_char_p
 for _n in ("rth_load_yaml", "rth_load_yaml_str", "rth_load_sg"):
@@ -276,6 +281,10 @@ class Context:
 
     def reset_stats(self):
         self._chk(_gpu.rtamd_reset_stats(self._h))
+
+    def count_work(self, on=True):
+        """Renders that follow also count the tests their traversals execute (Stats.tests_*)."""
+        self._chk(_gpu.rtamd_count_work(self._h, 1 if on else 0))
 
     def close(self, _destroy=_gpu.rtamd_ctx_destroy):
         if getattr(self, "_h", None):

@@ -38,7 +38,8 @@ struct rtamd_ctx {
     double* d_frames = nullptr;
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
-    int max_blocks[2][64] = {};  // [mode][variant]
+    int max_blocks[2][128] = {};  // [mode][variant]
+    bool count_work = false;       // launches use the kernels that count the tests they execute (rtamd_count_work)
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -134,7 +135,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->num_cus = prop.multiProcessorCount;
-    for (int v = 0; v < 64; v++) {
+    for (int v = 0; v < 128; v++) {
         int b = 0;
         if ((e = rtamd_occupancy_strict(v, &b)) != hipSuccess) return bail("occupancy(strict)", e);
         ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, b) * ctx->num_cus;
@@ -143,7 +144,7 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     }
     int mb = 0;
     for (int m = 0; m < 2; m++)
-        for (int c = 0; c < 64; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
+        for (int c = 0; c < 128; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
     if ((e = hipMalloc(&ctx->d_queue, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(queue)", e);
@@ -407,6 +408,9 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     // triangle keeps the intersection key of its place in the original order (leaf << RTAMD_KEY_SHIFT | slot), which
     // is what decides between equal t (src/scene.rs:19-26: stable sorts) and what shading looks the triangle up by.
     // CSG children are tested from the leaf table and keep the original runs.
+    // Diagnostic (measurements only): the traversal as the reference's World::intersect does it, every leaf and every
+    // triangle for every ray -- no pools cut again, no bounds on runs of triangles, no bounds records.
+    const bool brute = getenv("RTAMD_BRUTE_FORCE") != nullptr;
     std::vector<double> tri_sorted(s->tri_geom, s->tri_geom + (size_t)s->n_tris * 9);
     std::vector<int32_t> tri_key((size_t)s->n_tris, 0);
     std::vector<double> run_box(boxes);
@@ -433,7 +437,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             int j = i + 1;
             if (L.kind == RTAMD_MESH && !in_csg[(size_t)i] && has_box[(size_t)i])
                 while (j < s->n_leaves && same_object(i, j) && s->leaves[j].tri_start == s->leaves[j - 1].tri_start + s->leaves[j - 1].tri_count) j++;
-            if (j - i < 2) {
+            if (j - i < 2 || brute) {
                 i = j;
                 continue;
             }
@@ -612,6 +616,8 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             // the traversal needs the bounds for every run and the matrix only for the runs a ray comes near:
             // the bounds take the matrix's place in the record, the matrix stays in the leaf table
             std::memcpy(D.w2o, &run_box[(size_t)leaf * 6], 6 * sizeof(double));
+            if (brute)
+                for (int k = 0; k < 3; k++) D.w2o[k] = -INFINITY, D.w2o[3 + k] = INFINITY;
             for (int k = 6; k < 12; k++) D.w2o[k] = 0.0;
         }
         D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
@@ -653,6 +659,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     // its rays meets them.  A record that closes an equality class is skipped only when it is that whole class.
     std::vector<double> cone_dirs;
     auto with_bounds = [&](const std::vector<DVisit>& in) {
+        if (brute) return in;
         // A record that closes a class may be skipped only when it is the whole class (the record before it
         // closed the previous one): the container pass then has nothing pending when it is passed over.
         std::vector<char> groupable(in.size(), 0);
@@ -877,7 +884,8 @@ int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows) {
 // array instead of the context's own buffers, and nothing on the way allocates, frees or waits for the device.
 static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool static_scratch = false) {
     if (mode != RTAMD_MODE_STRICT && mode != RTAMD_MODE_FAST) return fail(ctx, RTAMD_E_INVALID, "unknown mode");
-    int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][ctx->variant], (w.n_pixels + 255) / 256);
+    const int variant = ctx->variant | (ctx->count_work ? 64 : 0);
+    int blocks = (int)std::min<int64_t>(ctx->max_blocks[mode][variant], (w.n_pixels + 255) / 256);
     blocks = std::max(blocks, 1);
     w.stats = ctx->d_stats;
     if (static_scratch) {
@@ -922,6 +930,7 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
     if (const char* e = getenv("RTAMD_REFILL_MIN")) w.refill_min = atoi(e);  // diagnostic
     w.mesh_few = 32;
     if (const char* e = getenv("RTAMD_MESH_FEW")) w.mesh_few = atoi(e);  // diagnostic: 0 = always the loop, 64 = never
+    if (getenv("RTAMD_BRUTE_FORCE")) w.mesh_few = 0;
     // (the table is memory the context allocates and fills with a blocking copy: not for static_scratch, whose
     // pixels are the same bits in another order of work)
     if (!static_scratch && !w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
@@ -970,8 +979,8 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
     }
     HIPCHK(ctx, hipMemsetAsync(w.queue_head, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
-    hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, ctx->variant, blocks, stream)
-                                             : rtamd_launch_fast(ctx->ds, w, ctx->variant, blocks, stream);
+    hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, variant, blocks, stream)
+                                             : rtamd_launch_fast(ctx->ds, w, variant, blocks, stream);
     if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
@@ -1106,6 +1115,10 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
     out->refract_rays = h[ST_REFRACT], out->container_passes = h[ST_CONTAINER];
     out->rays = h[ST_PRIMARY] + h[ST_SHADOW_RAYS] + h[ST_REFLECT] + h[ST_REFRACT] + h[ST_CONTAINER];
     out->shade_points = h[ST_SHADE_POINTS], out->light_samples = h[ST_LIGHT_SAMPLES], out->csg_overflows = h[ST_CSG_OVERFLOW];
+    out->tests_sphere = h[ST_T_SPHERE], out->tests_plane = h[ST_T_PLANE], out->tests_cube = h[ST_T_CUBE];
+    out->tests_slab2 = h[ST_T_SLAB2], out->tests_slab3 = h[ST_T_SLAB3], out->tests_cylinder = h[ST_T_CYLINDER];
+    out->tests_cone = h[ST_T_CONE], out->tests_caps = h[ST_T_CAPS], out->tests_tri_first = h[ST_T_TRI1];
+    out->tests_tri_second = h[ST_T_TRI2], out->tests_box = h[ST_T_BOX], out->tests_run_transform = h[ST_T_RUNX];
     if (getenv("RTAMD_PROFILE_DUMP")) {  // diagnostic builds (-DRTAMD_PROFILE) only
         const unsigned long long* p = slots.data() + ST_COUNT;
         if (p[3])
@@ -1121,6 +1134,12 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
         if (p[3] && ctx->stat_blocks > 1)
             fprintf(stderr, "[rtamd profile]   most iterations in one wave %llu, longest-running wave %llu cycles\n", q[6], q[7]);
     }
+    return RTAMD_OK;
+}
+
+int rtamd_count_work(rtamd_ctx* ctx, int on) {
+    if (!ctx) return RTAMD_E_INVALID;
+    ctx->count_work = on != 0;
     return RTAMD_OK;
 }
 

@@ -94,6 +94,20 @@ enum {
     ST_SHADE_POINTS,
     ST_LIGHT_SAMPLES,
     ST_CSG_OVERFLOW,
+    // work the traversal executed, in lane-tests: one ray against one leaf, box or triangle, counted for the lanes the
+    // test was meant for (a wave executes it for all 64)
+    ST_T_SPHERE,
+    ST_T_PLANE,
+    ST_T_CUBE,    // the reference's formula (cubes that are not axis-aligned, rays nearly parallel to a face, STRICT)
+    ST_T_SLAB2,   // axis-aligned cube, first two slabs (FAST)
+    ST_T_SLAB3,   // ... third slab and bookkeeping, for the rays the first two did not reject
+    ST_T_CYLINDER,
+    ST_T_CONE,
+    ST_T_CAPS,    // end caps of a closed cylinder or cone
+    ST_T_TRI1,    // triangle: determinant and u
+    ST_T_TRI2,    // triangle: v and t, for the rays the first half did not reject
+    ST_T_BOX,     // bounds records, boxes of runs of triangles and of CSG objects
+    ST_T_RUNX,    // ray transformed into the space of a run of triangles
     ST_COUNT
 };
 
@@ -101,7 +115,7 @@ enum {
 #define RTAMD_BLOCK_W 8          // a work-queue block: 64 pixels, this many wide (16 x 4 is no faster and writes as much)
 #define RTAMD_BLOCK_H (64 / RTAMD_BLOCK_W)
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
-#define RTAMD_STAT_STRIDE 16     // 64-bit words per block in the counter array
+#define RTAMD_STAT_STRIDE 32     // 64-bit words per block in the counter array (ST_COUNT counters, the rest for diagnostic builds)
 #define RTAMD_FRAME_F64_STRICT 22  // doubles per saved shade-point frame: STRICT keeps the whole shade point,
 #define RTAMD_FRAME_F64_FAST 8     // FAST the refraction ray it still owes (origin, direction, weight, budget)
 #define RTAMD_FRAME_F64 RTAMD_FRAME_F64_STRICT  // what the context's own buffer is sized for
@@ -136,6 +150,7 @@ struct DWork {
 // variant: base (0 scene without triangles and CSG, 1 with triangles, 2 with CSG, 3 with CSG objects of at most
 // RTAMD_CSG_LIST_SMALL possible intersections per ray) + 4 if there are axis-aligned cubes outside CSG objects
 // + 8 if there are cylinders or cones + 16 if the visit lists hold bounds records (bases 2 and 3 ignore all three)
+// + 32 CSG scene without triangles + 64 the twin that counts the tests it executes
 hipError_t rtamd_launch_strict(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_launch_fast(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_occupancy_strict(int variant, int* blocks_per_cu);

@@ -39,14 +39,27 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
         vals = list(by_dispatch.values())
         counters[name] = {"mean_per_dispatch": sum(vals) / len(vals), "dispatches": len(vals)}
 
-summary = {"workload": f"{scene} {W}x{H} {mode}", "kernel_avg_ns": kernel_avg_ns, "counters": counters}
+sys.path.insert(0, ROOT)
+import bench  # source_stamp(): which kernel sources these counters belong to
+
+summary = {"workload": f"{scene} {W}x{H} {mode}", "kernel_avg_ns": kernel_avg_ns, "counters": counters, "source_stamp": bench.source_stamp()}
+f64 = [counters.get(f"SQ_INSTS_VALU_{k}_F64", {}).get("mean_per_dispatch") for k in ("FMA", "MUL", "ADD")]
+if None not in f64 and kernel_avg_ns:
+    # wave-instructions x 64 lanes, fma = 2 flops: what the vector units issued in FP64 arithmetic (an upper bound on useful
+    # work: idle lanes of a wave and lanes a test was not meant for are counted too)
+    issued = (2 * f64[0] + f64[1] + f64[2]) * 64
+    summary["fp64_issued"] = {"flops_per_launch": issued, "tflops": issued / kernel_avg_ns / 1e3,
+                              "frac_of_78.6_tflops": issued / kernel_avg_ns / 1e3 / 78.6,
+                              "share_of_valu_instructions": sum(f64) / counters["SQ_INSTS_VALU"]["mean_per_dispatch"]
+                              if "SQ_INSTS_VALU" in counters else None}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     fetch_kb, write_kb = counters["FETCH_SIZE"]["mean_per_dispatch"], counters["WRITE_SIZE"]["mean_per_dispatch"]
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests as 64 bytes,
     # so the read side is doubled (an upper bound for narrow reads).
     hbm = {"fetch_size_kib": fetch_kb, "write_size_kib": write_kb, "read_bytes_corrected": 2 * fetch_kb * 1024,
            "write_bytes": write_kb * 1024, "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
-           "algorithmic_bytes_per_launch": W * H * 24, "source": f"profiles/{tag}_pmc_summary.json"}
+           "algorithmic_bytes_per_launch": W * H * 24, "source": f"profiles/{tag}_pmc_summary.json",
+           "source_stamp": bench.source_stamp()}
     summary["hbm"] = hbm
     json.dump(hbm, open(os.path.join(dst, f"pmc_hbm_{scene}_{W}x{H}_{mode}.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)

@@ -343,3 +343,45 @@ def test_rays_in_the_plane_of_a_cube_face(rt, oracle, gpu_ctx, tmp_path):
             rays.append([cx + sx * hx, 8, 0.25, 0, -1, 0])
     ref = _check_rays(rt, oracle, gpu_ctx, path, rays, remainings=(0, 2))
     assert (ref.sum(axis=1) > 0).mean() > 0.9  # the reference does hit
+
+
+# ------------------------------------------------------------------ executed-work counters
+@pytest.mark.parametrize("name", ["cover", "cylinders", "groups", "teapot_lowres_room", "csg"])
+def test_counting_kernels_render_the_same_frame_and_count(rt, gpu_ctx, manifest, name):
+    """rtamd_count_work switches to the kernels that count the tests their traversals execute.  The frame does not
+    change by a bit; the counters are zero without the switch; with it, every kind of leaf the scene has is counted,
+    no kind it lacks is, and no traversal tested more than the reference would (every leaf for every ray)."""
+    w, h = manifest[name]["small"]
+    flat = rt.Scene.from_sg(sg_path(name)).set_resolution(w, h).flatten()
+    gpu_ctx.upload(flat)
+    kinds = [flat.scene.leaves[i].kind for i in range(flat.scene.n_leaves)]
+    fields = ["tests_sphere", "tests_plane", "tests_cube", "tests_slab2", "tests_slab3", "tests_cylinder", "tests_cone", "tests_caps",
+              "tests_tri_first", "tests_tri_second", "tests_box", "tests_run_transform"]
+    for mode in (rt.MODE_FAST, rt.MODE_STRICT):
+        gpu_ctx.reset_stats()
+        plain = gpu_ctx.render(w, h, mode)
+        st = gpu_ctx.stats()
+        assert all(getattr(st, f) == 0 for f in fields)
+        try:
+            gpu_ctx.count_work(True)
+            gpu_ctx.reset_stats()
+            counted = gpu_ctx.render(w, h, mode)
+            st = gpu_ctx.stats()
+        finally:
+            gpu_ctx.count_work(False)
+        assert np.array_equal(plain, counted)
+        c = {f: getattr(st, f) for f in fields}
+        print(name, mode, c)
+        traversals = st.rays  # container passes included
+        per_kind = {0: c["tests_sphere"], 1: c["tests_plane"], 2: c["tests_cube"] + c["tests_slab2"], 3: c["tests_cylinder"],
+                    4: c["tests_cone"], 5: c["tests_run_transform"]}
+        for kind, n in per_kind.items():
+            have = kinds.count(kind)
+            assert (n > 0) == (have > 0), (kind, n, have)
+            # at most one test per leaf of that kind per traversal (a cube near a face plane is tested both ways)
+            assert n <= have * traversals * (2 if kind == 2 else 1)
+        assert c["tests_slab3"] <= c["tests_slab2"] and c["tests_tri_second"] <= c["tests_tri_first"]
+        if mode == rt.MODE_STRICT:
+            assert c["tests_slab2"] == 0
+        n_tris = flat.scene.n_tris
+        assert c["tests_tri_first"] <= n_tris * traversals and (c["tests_tri_first"] > 0) == (n_tris > 0)
