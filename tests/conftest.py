@@ -17,6 +17,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu on the GPU box)")
 
 
+# The command-line renderer is a program of its own, and a process that holds the GPU may not start another one: it is run
+# here, at the start of a session that asked for GPU tests and before anything in this process has touched the GPU; the
+# test that checks its output (tests/test_gpu_cli.py) finds the record below.
+CLI_RUNS = {}
+
+
+def pytest_sessionstart(session):
+    import subprocess
+    import tempfile
+    expr = session.config.getoption("-m") or ""
+    cli = os.path.join(ROOT, "ray-tracer_amd", "bin", "yaml_renderer")
+    if "gpu" not in expr or expr.strip().startswith("not") or not os.path.exists("/dev/kfd") or not os.path.exists(cli):
+        return
+    from test_host import YAML  # a scene of this repository's own (no file of the reference travels)
+    d = tempfile.mkdtemp(prefix="rtamd_cli_")
+    path = os.path.join(d, "own_scene.yaml")
+    with open(path, "w") as f:
+        f.write(YAML.replace("width: 20", "width: 200").replace("height: 10", "height: 100"))
+    CLI_RUNS["dir"], CLI_RUNS["yaml"] = d, path
+    for key, args in (("default", [path]), ("flags", [path, "--width", "96", "--height", "64", "--strict", "--ppm", "-o", os.path.join(d, "small.ppm")])):
+        try:
+            CLI_RUNS[key] = subprocess.run([cli] + args, cwd=d, capture_output=True, text=True, timeout=120)
+        except Exception as e:  # the test reports it
+            CLI_RUNS[key] = e
+
+
 def _built():
     need = [os.path.join(ROOT, "ray-tracer_amd", "lib", n) for n in ("librtamd.so", "librtamd_host.so")]
     need.append(os.path.join(ROOT, "oracle", "build", "liboracle.so"))

@@ -23,7 +23,7 @@ def _frame(rt, ctx, w, h, mode):
 
 CASES = [("cover", 3840, 2160, 3001), ("cylinders", 3840, 2160, 3001), ("tables", 3840, 2160, 3001),
          ("reflect_refract", 3840, 2160, 3001), ("glass_spheres", 7680, 4320, 9001), ("groups", 7680, 4320, 30011),
-         ("csg", 7680, 4320, 9001)]
+         ("csg", 7680, 4320, 9001), ("teapot_room", 3840, 2160, 27001)]
 
 
 @pytest.mark.parametrize("name,w,h,stride", CASES)
