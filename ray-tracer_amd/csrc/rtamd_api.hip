@@ -586,6 +586,38 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &d.materials))) return rc;
     if ((rc = upload(ctx, s->csg_nodes, (size_t)s->n_csg_nodes, &d.csg_nodes))) return rc;
     if ((rc = upload(ctx, s->csg_roots, (size_t)s->n_csg_roots, &d.csg_roots))) return rc;
+    {
+        // slot tables of small CSG objects (see DCsgSlot); larger objects get none and use the sorted lists
+        std::vector<DCsgSlot> slots;
+        std::vector<DCsgSlotNode> snodes((size_t)s->n_csg_nodes, DCsgSlotNode{0, 0, 0, 0});
+        std::vector<int32_t> slot0((size_t)s->n_csg_roots, 0);
+        for (int r = 0; csg_small && r < s->n_csg_roots; r++) {
+            const rtamd_csg_root& R = s->csg_roots[r];
+            slot0[(size_t)r] = (int32_t)slots.size();
+            std::vector<int> first((size_t)(R.leaf_hi - R.leaf_lo) + 1, 0);  // first slot of every leaf, relative to the root
+            for (int l = R.leaf_lo; l < R.leaf_hi; l++) {
+                const rtamd_leaf& L = s->leaves[l];
+                const int n = L.kind == RTAMD_PLANE ? 1 : L.kind == RTAMD_MESH ? L.tri_count : (L.kind == RTAMD_CYLINDER || L.kind == RTAMD_CONE) ? 4 : 2;
+                first[(size_t)(l - R.leaf_lo) + 1] = first[(size_t)(l - R.leaf_lo)] + n;
+                for (int k = 0; k < n; k++)
+                    slots.push_back(DCsgSlot{(int32_t)(((uint32_t)l << RTAMD_KEY_SHIFT) | (uint32_t)k), L.eq_class, (L.flags & RTAMD_LEAF_SHADOW) ? 1u : 0u, 0u});
+            }
+            auto bits = [&](int la, int lb) {  // slots of leaves [la, lb)
+                const int a = first[(size_t)(la - R.leaf_lo)], b = first[(size_t)(lb - R.leaf_lo)];
+                return (b >= 32 ? 0xffffffffu : ((1u << b) - 1u)) & ~((1u << a) - 1u);
+            };
+            for (int q = R.node_start; q < R.node_start + R.node_count; q++) {
+                const rtamd_csg_node& N = s->csg_nodes[q];
+                DCsgSlotNode& D = snodes[(size_t)q];
+                D.range = bits(N.leaf_lo, N.leaf_hi), D.op = N.op, D.left = 0;
+                for (int l = N.leaf_lo; l < N.leaf_hi; l++)
+                    if ((N.left_mask >> (l - N.leaf_lo)) & 1ull) D.left |= bits(l, l + 1);
+            }
+        }
+        if ((rc = upload(ctx, slots.data(), slots.size(), &d.csg_slots))) return rc;
+        if ((rc = upload(ctx, snodes.data(), snodes.size(), &d.csg_slot_nodes))) return rc;
+        if ((rc = upload(ctx, slot0.data(), slot0.size(), &d.csg_slot0))) return rc;
+    }
     std::vector<DVisit> dv((size_t)s->n_visits);
     std::vector<int32_t> class_mat((size_t)std::max(s->n_classes, 1), 0);
     double diag_thr = 0.0;

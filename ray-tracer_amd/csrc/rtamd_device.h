@@ -57,6 +57,23 @@ struct alignas(16) DVisit {
 #define DVISIT_BOUNDS 6u  // kind of a bounds record: w2o[0..5] = lo xyz, hi xyz (world space); unit = records to skip;
                           // with DBOUNDS_HAS_CONE the bytes of p0 hold int32 start, count of its list in DScene::cone_dirs
 
+// Small CSG objects (at most RTAMD_CSG_LIST_SMALL possible intersections on a ray) are evaluated without a sorted list:
+// every possible intersection has a fixed slot -- the leaves of the object in depth-first order, each with its 2
+// (sphere, cube), 1 (plane, triangle) or 4 (cylinder, cone) slots -- and the tables below say, per slot and per node,
+// what the filter of src/shapes/csg.rs:54-82 needs.
+struct DCsgSlot {
+    int32_t key;       // leaf << RTAMD_KEY_SHIFT | slot inside the leaf
+    int32_t eq_class;  // of the leaf
+    uint32_t shadow;   // the leaf takes part in is_shadowed
+    uint32_t pad_;
+};
+struct DCsgSlotNode {  // one per CSG node, in the order of rtamd_csg_node
+    uint32_t range;  // slots of the leaves below this node
+    uint32_t left;   // ... of those that `left.includes` (src/shapes/csg.rs:64)
+    int32_t op;
+    uint32_t pad_;
+};
+
 struct DScene {
     rtamd_camera cam;
     int32_t max_remaining;
@@ -79,6 +96,9 @@ struct DScene {
     const rtamd_material* materials;
     const rtamd_csg_node* csg_nodes;
     const rtamd_csg_root* csg_roots;
+    const DCsgSlot* csg_slots;         // small CSG objects only (kernel variant 3): slots of root r start at csg_slot0[r]
+    const DCsgSlotNode* csg_slot_nodes;
+    const int32_t* csg_slot0;
     const DVisit* visits;      // grouped by equality class: the order container passes need
     const DVisit* visits_dfs;  // one record per plain leaf / top-most CSG object in depth-first order
     const int32_t* class_material;  // material of each equality class
@@ -111,7 +131,7 @@ enum {
     ST_COUNT
 };
 
-#define RTAMD_CSG_LIST_SMALL 12  // list length of the kernel variant for small CSG objects
+#define RTAMD_CSG_LIST_SMALL 8  // most intersections one CSG object can put on a ray for the list-free kernel variant
 #define RTAMD_BLOCK_W 8          // a work-queue block: 64 pixels, this many wide (16 x 4 is no faster and writes as much)
 #define RTAMD_BLOCK_H (64 / RTAMD_BLOCK_W)
 #define RTAMD_KEY_SHIFT 12       // intersection key = leaf index << 12 | slot inside the leaf (RTAMD_MAX_MESH_TRIS = 4096)
