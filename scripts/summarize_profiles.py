@@ -18,12 +18,19 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
+def timed_kernel(name):
+    """The kernel the timed frames of bench.py run: the arithmetic mode asked for, not its counting twin (bench.py also
+    renders one frame with the counting kernel and, in fast mode, three with the strict one)."""
+    base = name.split("(")[0]
+    return base.startswith(f"rtamd_render_{mode}_") and not base.endswith("_count")
+
+
 stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
 kernel_avg_ns = None
 if stats:
     shutil.copyfile(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
     for row in csv.DictReader(open(stats[0])):
-        if row["Name"].startswith("rtamd_render"):
+        if timed_kernel(row["Name"]):
             kernel_avg_ns = float(row["AverageNs"])
             kernel_name = row["Name"]
 
@@ -31,7 +38,7 @@ counters = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     per = {}
     for row in csv.DictReader(open(f)):
-        if not row["Kernel_Name"].startswith("rtamd_render"):
+        if not timed_kernel(row["Kernel_Name"]):
             continue
         per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
@@ -42,7 +49,7 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
 sys.path.insert(0, ROOT)
 import bench  # source_stamp(): which kernel sources these counters belong to
 
-summary = {"workload": f"{scene} {W}x{H} {mode}", "kernel_avg_ns": kernel_avg_ns, "counters": counters, "source_stamp": bench.source_stamp()}
+summary = {"workload": f"{scene} {W}x{H} {mode}", "kernel": kernel_name if kernel_avg_ns else None, "kernel_avg_ns": kernel_avg_ns, "counters": counters, "source_stamp": bench.source_stamp()}
 f64 = [counters.get(f"SQ_INSTS_VALU_{k}_F64", {}).get("mean_per_dispatch") for k in ("FMA", "MUL", "ADD")]
 if None not in f64 and kernel_avg_ns:
     # wave-instructions x 64 lanes, fma = 2 flops: what the vector units issued in FP64 arithmetic (an upper bound on useful
