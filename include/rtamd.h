@@ -250,6 +250,49 @@ int rtamd_count_work(rtamd_ctx* ctx, int on);
 int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out);
 int rtamd_reset_stats(rtamd_ctx* ctx);
 
+/* ---- Several GPUs, one frame.  No counterpart in the reference: its pixel loop (src/scene.rs:240-246) is one thread;
+ * what makes the split possible is that its pixels are independent.  A host in any language gets an assembled frame
+ * from N GPUs through these calls; no collective library, no Python. */
+
+/* Where the rows of a rows-spec lie in the frame: `n_chunks` runs of `chunk_rows` rows that start at rows
+ * first_row, first_row + stride_rows, ..., and after them a last run of `tail_rows` rows (0: none) at
+ * first_row + n_chunks * stride_rows.  The compact output of rtamd_render_rows holds them in that order.  Pure
+ * arithmetic (no context, no GPU): a host that moves the rows itself -- ncclSend / ncclRecv, MPI, its own peer
+ * copies -- copies runs instead of rows. */
+typedef struct rtamd_layout {
+    int64_t first_row, chunk_rows, stride_rows, n_chunks, tail_rows;
+} rtamd_layout;
+int rtamd_rows_layout(int vsize, const rtamd_rows* rows, rtamd_layout* out);
+
+typedef struct rtamd_multi rtamd_multi;
+
+/* One context per entry of `devices` (1..64 entries; an entry may repeat).  Rank 0 -- devices[0] -- holds the
+ * assembled frame; every other GPU must be able to write to it (peer access, xGMI on an MI355X node). */
+int rtamd_multi_create(const int* devices, int n_devices, rtamd_multi** out);
+void rtamd_multi_destroy(rtamd_multi* m);
+const char* rtamd_multi_last_error(const rtamd_multi* m); /* m may be NULL: creation errors */
+
+/* rtamd_scene_upload to every rank (the scene is small and read-only: replicated, not partitioned). */
+int rtamd_multi_upload(rtamd_multi* m, const rtamd_scene* scene);
+
+#define RTAMD_WANT_F64 1
+#define RTAMD_WANT_U8 2
+/* Camera::render over all ranks: rows in tiles of `tile_rows`, tile i in part i % n_parts, rank 0 renders the first
+ * `first_parts` parts and every other rank `other_parts` (n_parts = first_parts + (n - 1) * other_parts; 1, 1 is the
+ * plain cyclic split -- rank 0's rows do not travel, so a larger share for it can pay).  Every rank renders into a
+ * buffer on its own GPU and writes its runs of rows into the frame on rank 0's GPU (one strided copy per rank, each
+ * over its own link).  The frame is copied to h_rgb / h_rgb8 where those are not NULL; `want` (RTAMD_WANT_*) asks for
+ * a frame that stays on the device (rtamd_multi_frame).  Blocking.  Same pixels as rtamd_render, to the bit. */
+int rtamd_multi_render(rtamd_multi* m, int mode, int tile_rows, int first_parts, int other_parts, double* h_rgb, uint8_t* h_rgb8, int want);
+
+/* Device pointers (on devices[0]) of the frame the last rtamd_multi_render assembled; NULL for a kind it was not asked for. */
+int rtamd_multi_frame(rtamd_multi* m, double** d_rgb, uint8_t** d_rgb8);
+
+/* Counters summed over the ranks (kernel_ms: the slowest rank's kernel), and per rank (arrays of n_devices, may be
+ * NULL) the time of its render kernel and of putting its rows in place in the last rtamd_multi_render. */
+int rtamd_multi_get_stats(rtamd_multi* m, rtamd_stats* total, double* render_ms, double* place_ms);
+int rtamd_multi_reset_stats(rtamd_multi* m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,7 +67,9 @@ class Rows(C.Structure):
 # every symbol include/rtamd.h declares
 GPU_SYMBOLS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error", "rtamd_scene_upload", "rtamd_part_rows",
                "rtamd_render_rows", "rtamd_render_rows_static", "rtamd_render", "rtamd_host_alloc", "rtamd_host_free", "rtamd_color_at", "rtamd_get_stats",
-               "rtamd_reset_stats", "rtamd_count_work"]
+               "rtamd_reset_stats", "rtamd_count_work", "rtamd_rows_layout", "rtamd_multi_create", "rtamd_multi_destroy",
+               "rtamd_multi_last_error", "rtamd_multi_upload", "rtamd_multi_render", "rtamd_multi_frame", "rtamd_multi_get_stats",
+               "rtamd_multi_reset_stats"]
 
 _gpu.rtamd_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
 _gpu.rtamd_ctx_create.restype = C.c_int
@@ -97,6 +99,31 @@ _gpu.rtamd_reset_stats.argtypes = [C.c_void_p]
 _gpu.rtamd_reset_stats.restype = C.c_int
 _gpu.rtamd_count_work.argtypes = [C.c_void_p, C.c_int]
 _gpu.rtamd_count_work.restype = C.c_int
+
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("first_row", "chunk_rows", "stride_rows", "n_chunks", "tail_rows")]
+
+
+_gpu.rtamd_rows_layout.argtypes = [C.c_int, C.POINTER(Rows), C.POINTER(Layout)]
+_gpu.rtamd_rows_layout.restype = C.c_int
+_gpu.rtamd_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+_gpu.rtamd_multi_create.restype = C.c_int
+_gpu.rtamd_multi_destroy.argtypes = [C.c_void_p]
+_gpu.rtamd_multi_destroy.restype = None
+_gpu.rtamd_multi_last_error.argtypes = [C.c_void_p]
+_gpu.rtamd_multi_last_error.restype = C.c_char_p
+_gpu.rtamd_multi_upload.argtypes = [C.c_void_p, C.c_void_p]
+_gpu.rtamd_multi_upload.restype = C.c_int
+_gpu.rtamd_multi_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+_gpu.rtamd_multi_render.restype = C.c_int
+_gpu.rtamd_multi_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+_gpu.rtamd_multi_frame.restype = C.c_int
+_gpu.rtamd_multi_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_void_p, C.c_void_p]
+_gpu.rtamd_multi_get_stats.restype = C.c_int
+_gpu.rtamd_multi_reset_stats.argtypes = [C.c_void_p]
+_gpu.rtamd_multi_reset_stats.restype = C.c_int
 
 _host.rth_last_error.restype = C.c_char_p
 for _n in ("rth_load_yaml", "rth_load_yaml_str", "rth_load_sg"):
@@ -287,6 +314,74 @@ class Context:
         self._chk(_gpu.rtamd_count_work(self._h, 1 if on else 0))
 
     def close(self, _destroy=_gpu.rtamd_ctx_destroy):
+        if getattr(self, "_h", None):
+            _destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def rows_layout(vsize, tile_rows, part, n_parts, span=1):
+    """rtamd_rows_layout: where the rows of a rows-spec lie in the frame (pure arithmetic, no GPU)."""
+    r, out = Rows(tile_rows, part, n_parts, span), Layout()
+    if _gpu.rtamd_rows_layout(vsize, C.byref(r), C.byref(out)):
+        raise RtamdError("bad rows specification")
+    return {n: getattr(out, n) for n, _ in out._fields_}
+
+
+WANT_F64, WANT_U8 = 1, 2
+
+
+class MultiContext:
+    """Several GPUs, one frame (``rtamd_multi``): one context per entry of ``devices``, frame assembled on the first."""
+
+    def __init__(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        p = C.c_void_p()
+        rc = _gpu.rtamd_multi_create(arr, len(devices), C.byref(p))
+        if rc:
+            raise RtamdError(f"rtamd_multi_create({list(devices)}) = {rc}: {_gpu.rtamd_multi_last_error(None).decode()}")
+        self._h, self.n = p, len(devices)
+        self._flat = None
+
+    def _chk(self, rc):
+        if rc:
+            raise RtamdError(f"rtamd error {rc}: {_gpu.rtamd_multi_last_error(self._h).decode()}")
+
+    def upload(self, flat):
+        self._chk(_gpu.rtamd_multi_upload(self._h, flat.view))
+        self._flat = flat
+        self._size = (flat.scene.camera.hsize, flat.scene.camera.vsize)
+        return self
+
+    def render(self, mode=MODE_FAST, tile_rows=8, first_parts=1, other_parts=1, want_u8=False):
+        """Whole frame assembled on the first GPU and copied into host arrays."""
+        w, h = self._size
+        rgb = np.empty((h, w, 3), dtype=np.float64)
+        u8 = np.empty((h, w, 3), dtype=np.uint8) if want_u8 else None
+        self._chk(_gpu.rtamd_multi_render(self._h, mode, tile_rows, first_parts, other_parts, rgb.ctypes.data,
+                                          u8.ctypes.data if want_u8 else None, 0))
+        return (rgb, u8) if want_u8 else rgb
+
+    def render_on_device(self, mode=MODE_FAST, tile_rows=8, first_parts=1, other_parts=1, want=WANT_F64):
+        """The frame stays on the first GPU; returns its device addresses (f64, u8; 0 for a kind not asked for)."""
+        self._chk(_gpu.rtamd_multi_render(self._h, mode, tile_rows, first_parts, other_parts, None, None, want))
+        a, b = C.c_void_p(), C.c_void_p()
+        self._chk(_gpu.rtamd_multi_frame(self._h, C.byref(a), C.byref(b)))
+        return (a.value or 0) if want & WANT_F64 else 0, (b.value or 0) if want & WANT_U8 else 0
+
+    def stats(self):
+        """(Stats summed over the ranks, render ms per rank, ms per rank of putting its rows in place)."""
+        st = Stats()
+        r, p = np.zeros(self.n), np.zeros(self.n)
+        self._chk(_gpu.rtamd_multi_get_stats(self._h, C.byref(st), r.ctypes.data, p.ctypes.data))
+        return st, r, p
+
+    def reset_stats(self):
+        self._chk(_gpu.rtamd_multi_reset_stats(self._h))
+
+    def close(self, _destroy=_gpu.rtamd_multi_destroy):
         if getattr(self, "_h", None):
             _destroy(self._h)
             self._h = None

@@ -1,6 +1,7 @@
 """Host-side logic that runs without a GPU: loaders, canvas output, scene flattening, the C ABI's
 symbols, and the absence of any CPU fallback."""
 import ctypes as C
+import importlib
 import os
 import re
 import subprocess
@@ -333,3 +334,21 @@ def test_bench_refuses_to_run_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
+
+
+def test_rows_layout_is_the_rows_rule_as_runs(rt):
+    """rtamd_rows_layout (what a host that moves the rows itself copies by) against the rule rows.py states row by row."""
+    rows_mod = importlib.import_module("ray-tracer_amd.rows")
+    for vsize in (0, 1, 7, 8, 77, 100, 2160):
+        for tile_rows, part, n_parts, span in ((8, 0, 1, 1), (8, 1, 2, 1), (8, 7, 8, 1), (3, 2, 5, 2), (100, 0, 2, 1), (8, 0, 9, 2), (8, 2, 9, 1),
+                                               (5, 3, 7, 4), (1, 0, 3, 3)):
+            lay = rt.rows_layout(vsize, tile_rows, part, n_parts, span)
+            rows = []
+            for c in range(lay["n_chunks"]):
+                start = lay["first_row"] + c * lay["stride_rows"]
+                rows += list(range(start, start + lay["chunk_rows"]))
+            start = lay["first_row"] + lay["n_chunks"] * lay["stride_rows"]
+            rows += list(range(start, start + lay["tail_rows"]))
+            assert rows == rows_mod.part_row_indices(vsize, tile_rows, part, n_parts, span).tolist(), (vsize, tile_rows, part, n_parts, span)
+    with pytest.raises(rt.RtamdError):
+        rt.rows_layout(10, 8, 2, 2)
