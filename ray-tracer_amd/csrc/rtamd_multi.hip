@@ -70,15 +70,17 @@ const char* rtamd_multi_last_error(const rtamd_multi* m) { return m ? m->err.c_s
 void rtamd_multi_destroy(rtamd_multi* m) {
     if (!m) return;
     for (auto& r : m->ranks) {
+        if (!r.ctx) continue;  // (a rank whose creation failed: its device index may not even exist)
         (void)hipSetDevice(r.device);
         if (r.stream) (void)hipStreamSynchronize(r.stream);
     }
-    if (!m->ranks.empty()) {
+    if (!m->ranks.empty() && m->ranks[0].ctx) {
         (void)hipSetDevice(m->ranks[0].device);
         if (m->frame) (void)hipFree(m->frame);
         if (m->frame8) (void)hipFree(m->frame8);
     }
     for (auto& r : m->ranks) {
+        if (!r.ctx) continue;
         (void)hipSetDevice(r.device);
         if (r.part) (void)hipFree(r.part);
         if (r.part8) (void)hipFree(r.part8);
