@@ -184,6 +184,8 @@ typedef struct rtamd_stats {
     uint64_t tests_tri_second; /* ... v and t (:69-80), only for rays the first half did not reject */
     uint64_t tests_box;        /* bounds of leaf groups, triangle runs, CSG objects (no counterpart in the reference) */
     uint64_t tests_run_transform; /* Ray::transform into the space of a run of triangles (src/ray.rs:18-23) */
+    uint64_t team_shade_points; /* of shade_points: those whose shadow rays went to the lanes beside the pixel's own, all
+                                   lights at once (small frames, fast arithmetic; same pixels) -- always counted */
 } rtamd_stats;
 
 typedef struct rtamd_ctx rtamd_ctx;

@@ -54,7 +54,7 @@ class Stats(C.Structure):
                [("kernel_ms", C.c_double)] + \
                [(n, C.c_uint64) for n in ("tests_sphere", "tests_plane", "tests_cube", "tests_slab2", "tests_slab3", "tests_cylinder",
                                           "tests_cone", "tests_caps", "tests_tri_first", "tests_tri_second", "tests_box",
-                                          "tests_run_transform")]
+                                          "tests_run_transform", "team_shade_points")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -38,7 +38,7 @@ struct rtamd_ctx {
     double* d_frames = nullptr;
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
-    int max_blocks[2][128] = {};  // [mode][variant]
+    int max_blocks[3][128] = {};  // [mode][variant]; [2]: the fast kernels with teams of lanes per pixel
     bool count_work = false;       // launches use the kernels that count the tests they execute (rtamd_count_work)
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -49,7 +49,9 @@ struct rtamd_ctx {
     std::vector<std::array<int, 4>> costly;
     int32_t* d_order = nullptr;  // queue position -> group of 64 pixels, for the partition of the frame in order_key
     size_t order_cap = 0;
-    std::array<int64_t, 6> order_key{{-1, -1, -1, -1, -1, -1}};
+    std::array<int64_t, 8> order_key{{-1, -1, -1, -1, -1, -1, -1, -1}};
+    size_t order_hot = 0, order_len = 0;  // groups the table puts first; its entries
+    int order_teams = 1;                  // lanes per pixel in the groups it marks
     bool order_used = false;
     // device-side frame of rtamd_render (host destination), kept between calls
     double* d_out = nullptr;
@@ -141,9 +143,11 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
         ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, b) * ctx->num_cus;
         if ((e = rtamd_occupancy_fast(v, &b)) != hipSuccess) return bail("occupancy(fast)", e);
         ctx->max_blocks[RTAMD_MODE_FAST][v] = std::max(1, b) * ctx->num_cus;
+        if ((e = rtamd_occupancy_teams(v, &b)) != hipSuccess) return bail("occupancy(teams)", e);
+        ctx->max_blocks[2][v] = std::max(1, b) * ctx->num_cus;
     }
     int mb = 0;
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < 3; m++)
         for (int c = 0; c < 128; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
@@ -836,7 +840,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
     // ---- where on the screen the costly leaves are (empty list: no preference)
     ctx->costly.clear();
-    ctx->order_key = {{-1, -1, -1, -1, -1, -1}};
+    ctx->order_key = {{-1, -1, -1, -1, -1, -1, -1, -1}};
     {
         bool usable = cam_ok;
         for (int i = 0; usable && i < s->n_leaves; i++) {
@@ -963,12 +967,24 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
     w.mesh_few = 32;
     if (const char* e = getenv("RTAMD_MESH_FEW")) w.mesh_few = atoi(e);  // diagnostic: 0 = always the loop, 64 = never
     if (getenv("RTAMD_BRUTE_FORCE")) w.mesh_few = 0;
+    // Teams of lanes per pixel for the groups the table below marks (FAST kernels): they halve the chains of dependent rays at
+    // the price of idle lanes, which pays when the frame (or this rank's part of it) is too small to fill the GPU many times
+    // over -- then the longest chain, not the throughput, is what the frame waits for.  Same pixels either way.
+    int teams = 1, teams_rule = 0;  // rule: 0 never, 1 when every piece of work gets a wave at once, 2 whenever allowed
+    if (mode == RTAMD_MODE_FAST && !static_scratch && !ctx->count_work && ctx->ds.n_lights >= 1 && ctx->ds.n_lights <= 3) {
+        const char* e = getenv("RTAMD_TEAMS");  // diagnostic: 0 never, 1 whenever the scene allows
+        teams_rule = e ? (atoi(e) != 0 ? 2 : 0) : 1;
+        teams = ctx->ds.n_lights == 1 ? 2 : 4;
+    }
+    const int64_t wave_slots = (int64_t)ctx->max_blocks[2][variant & 63] * 4;  // (of the kernels with teams)
+    w.team = 1;
+    w.n_queue = w.n_groups;
     // (the table is memory the context allocates and fills with a blocking copy: not for static_scratch, whose
     // pixels are the same bits in another order of work)
     if (!static_scratch && !w.custom_rays && !ctx->costly.empty() && w.n_groups > 1 && w.n_groups < (int64_t)1 << 31) {
         // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
         // The table depends on the partition of the frame only: it is kept until that changes.
-        const std::array<int64_t, 6> key{{w.hsize, w.vsize, w.tile_rows, w.part, w.n_parts, w.span}};
+        const std::array<int64_t, 8> key{{w.hsize, w.vsize, w.tile_rows, w.part, w.n_parts, w.span, teams_rule ? teams : 1, teams_rule == 1 ? wave_slots : 0}};
         if (key != ctx->order_key) {
             ctx->order_used = false;
             std::vector<int32_t> first, rest;
@@ -992,7 +1008,19 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
                 }
                 (hot ? first : rest).push_back((int32_t)grp);
             }
-            if (!first.empty() && !rest.empty()) {
+            if (!first.empty() && w.n_groups < ((int64_t)1 << 29)) {
+                // the groups a kernel may give a team of lanes per pixel: marked in the sign bit; with teams such a group
+                // is handed out in `team` pieces (bits 29-30), one per queue entry, so that its pixels spread over as many waves
+                ctx->order_hot = first.size();
+                if (teams_rule == 0 || (teams_rule == 1 && w.n_groups + (int64_t)first.size() * (teams - 1) > wave_slots)) teams = 1;
+                ctx->order_teams = teams;
+                if (teams > 1) {
+                    std::vector<int32_t> pieces;
+                    pieces.reserve(first.size() * (size_t)teams);
+                    for (int32_t g : first)
+                        for (int k = 0; k < teams; k++) pieces.push_back((int32_t)(0x80000000u | ((uint32_t)k << 29) | (uint32_t)g));
+                    first.swap(pieces);
+                }
                 first.insert(first.end(), rest.begin(), rest.end());
                 if (first.size() > ctx->order_cap) {
                     HIPCHK(ctx, hipDeviceSynchronize());
@@ -1001,17 +1029,26 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
                     HIPCHK(ctx, hipMalloc(&ctx->d_order, first.size() * sizeof(int32_t)));
                     ctx->order_cap = first.size();
                 }
+                if (getenv("RTAMD_UPLOAD_DUMP")) {  // diagnostic
+                    fprintf(stderr, "[rtamd order] groups %lld hot %zu teams %d entries %zu:", (long long)w.n_groups, ctx->order_hot, teams, first.size());
+                    for (size_t q = 0; q < std::min<size_t>(first.size(), 40); q++) fprintf(stderr, " %08x", (unsigned)first[q]);
+                    fprintf(stderr, "\n");
+                }
                 HIPCHK(ctx, hipDeviceSynchronize());  // an earlier launch may still read the table
                 HIPCHK(ctx, hipMemcpy(ctx->d_order, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
                 ctx->order_used = true;
+                ctx->order_len = first.size();
             }
             ctx->order_key = key;
         }
-        if (ctx->order_used) w.order = ctx->d_order;
+        if (ctx->order_used) w.order = ctx->d_order, w.n_queue = (int64_t)ctx->order_len, w.team = ctx->order_teams;
     }
+    if (w.team > 1)  // (pieces of groups are units of work like groups: a wave each)
+        blocks = (int)std::min<int64_t>(ctx->max_blocks[2][variant & 63], (w.n_queue + 3) / 4);
     HIPCHK(ctx, hipMemsetAsync(w.queue_head, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, variant, blocks, stream)
+                   : w.team > 1              ? rtamd_launch_teams(ctx->ds, w, variant & 63, blocks, stream)
                                              : rtamd_launch_fast(ctx->ds, w, variant, blocks, stream);
     if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
@@ -1151,6 +1188,7 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
     out->tests_slab2 = h[ST_T_SLAB2], out->tests_slab3 = h[ST_T_SLAB3], out->tests_cylinder = h[ST_T_CYLINDER];
     out->tests_cone = h[ST_T_CONE], out->tests_caps = h[ST_T_CAPS], out->tests_tri_first = h[ST_T_TRI1];
     out->tests_tri_second = h[ST_T_TRI2], out->tests_box = h[ST_T_BOX], out->tests_run_transform = h[ST_T_RUNX];
+    out->team_shade_points = h[ST_TEAM_POINTS];
     if (getenv("RTAMD_PROFILE_DUMP")) {  // diagnostic builds (-DRTAMD_PROFILE) only
         const unsigned long long* p = slots.data() + ST_COUNT;
         if (p[3])

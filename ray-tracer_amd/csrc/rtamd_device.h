@@ -128,6 +128,7 @@ enum {
     ST_T_TRI2,    // triangle: v and t, for the rays the first half did not reject
     ST_T_BOX,     // bounds records, boxes of runs of triangles and of CSG objects
     ST_T_RUNX,    // ray transformed into the space of a run of triangles
+    ST_TEAM_POINTS,  // shade points whose shadow rays a team of lanes traced side by side
     ST_COUNT
 };
 
@@ -149,7 +150,8 @@ struct DWork {
     int32_t tile_rows, part, n_parts, span;  // tiles i with i % n_parts in [part, part + span)
     int32_t remaining;          // recursion budget of the primary rays
     int64_t n_pixels;           // pixels of this part (or number of custom rays)
-    int64_t n_groups;           // the units of the work queue: groups of 64 pixels
+    int64_t n_groups;           // groups of 64 pixels
+    int64_t n_queue;            // entries of the work queue: one per group, `team` per group that `order` marks
     int32_t gcols, n_rows;      // gcols != 0: a group is a block of RTAMD_BLOCK_W x RTAMD_BLOCK_H pixels, gcols blocks side by side, over the part's
                                 // n_rows rows; gcols == 0: a group is 64 consecutive pixels (ceil(n_pixels / 64) groups)
     int64_t group_stride;       // coprime to n_groups: queue position g stands for pixel group (g * stride) % n_groups
@@ -157,6 +159,7 @@ struct DWork {
     const int32_t* order;       // NULL: groups in strided order; else queue position -> group of 64 pixels
     int32_t refill_min;         // a wave asks for its next group of pixels when at least this many of its lanes are idle
     int32_t mesh_few;           // a run of triangles that at most this many rays of a wave come near is tested one triangle per lane
+    int32_t team;               // lanes per pixel (2 or 4) in the groups `order` marks with its sign bit; 1: no such groups
     double* out_rgb;            // may be NULL
     uint8_t* out_rgb8;          // may be NULL
     // scratch the library owns
@@ -175,3 +178,6 @@ hipError_t rtamd_launch_strict(const DScene& s, const DWork& w, int variant, int
 hipError_t rtamd_launch_fast(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_occupancy_strict(int variant, int* blocks_per_cu);
 hipError_t rtamd_occupancy_fast(int variant, int* blocks_per_cu);
+// the fast kernels with teams of lanes per pixel (variant: without the counting bit)
+hipError_t rtamd_launch_teams(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
+hipError_t rtamd_occupancy_teams(int variant, int* blocks_per_cu);
