@@ -22,7 +22,8 @@ def timed_kernel(name):
     """The kernel the timed frames of bench.py run: the arithmetic mode asked for, not its counting twin (bench.py also
     renders one frame with the counting kernel and, in fast mode, three with the strict one)."""
     base = name.split("(")[0]
-    return base.startswith(f"rtamd_render_{mode}_") and not base.endswith("_count")
+    prefixes = (f"rtamd_render_{mode}_",) + (("rtamd_render_teams_",) if mode == "fast" else ())  # (small frames: the kernels with teams)
+    return base.startswith(prefixes) and not base.endswith("_count")
 
 
 stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
