@@ -748,11 +748,13 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             return B;
         };
         // A bounds record costs about as much as two tests of an axis-aligned cube; it is worth having when
-        // what it can save is several times that.  Rough costs in instructions per wave.
+        // what it can save is at least that.  Rough costs in instructions per wave.
         // A wave passes over the records only if all of its rays miss the box; the share of the frame outside the
         // box's picture says how often that can happen for the rays that start at the camera.
         const double kBoundsCost = 45.0;
-        const double kWorthIt = getenv("RTAMD_BOUNDS_WORTH") ? atof(getenv("RTAMD_BOUNDS_WORTH")) : 2.0;  // (diagnostic override)
+        // (break-even for the rays that start at the camera; measured: 1.0 beats 2.0 by 5 % on cover.yaml, whose cubes then
+        // get records over clusters of 2 to 11, and is within the noise of it elsewhere; 0 -- a record at every node -- and 4 lose)
+        const double kWorthIt = getenv("RTAMD_BOUNDS_WORTH") ? atof(getenv("RTAMD_BOUNDS_WORTH")) : 1.0;  // (diagnostic override)
         auto outside = [&](const DVisit& B) {
             double r[4];
             if (!screen_rect(B.w2o, r)) return 0.0;
@@ -853,6 +855,17 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         return out;
     };
     dv_dfs = with_bounds(dv_dfs);
+    if (getenv("RTAMD_UPLOAD_DUMP")) {  // diagnostic: the depth-first list, B<n> = bounds record over the next n records
+        fprintf(stderr, "[rtamd upload] depth-first list:");
+        for (const DVisit& v : dv_dfs) {
+            const uint32_t k = v.kind_flags & 0xffu;
+            if (k == DVISIT_BOUNDS)
+                fprintf(stderr, " B%d", v.unit);
+            else
+                fprintf(stderr, " %c", k == RTAMD_MESH ? 'm' : k == RTAMD_CUBE ? 'c' : k == RTAMD_SPHERE ? 's' : k == RTAMD_PLANE ? 'p' : 'q');
+        }
+        fprintf(stderr, "\n");
+    }
     // runs of axis-aligned cubes with the same shadow flag: every record carries the length of the rest of its run
     for (size_t i = dv_dfs.size(); i-- > 0;) {
         const uint32_t want = (uint32_t)RTAMD_CUBE | (DLEAF_DIAG << 8), mask = 0xffu | (DLEAF_DIAG << 8);
