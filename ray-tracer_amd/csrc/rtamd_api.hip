@@ -748,13 +748,19 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             return B;
         };
         // A bounds record costs about as much as two tests of an axis-aligned cube; it is worth having when
-        // what it can save is at least that.  Rough costs in instructions per wave.
+        // what it can save is about that.  Rough costs in instructions per wave.
         // A wave passes over the records only if all of its rays miss the box; the share of the frame outside the
         // box's picture says how often that can happen for the rays that start at the camera.
         const double kBoundsCost = 45.0;
-        // (break-even for the rays that start at the camera; measured: 1.0 beats 2.0 by 5 % on cover.yaml, whose cubes then
-        // get records over clusters of 2 to 11, and is within the noise of it elsewhere; 0 -- a record at every node -- and 4 lose)
-        const double kWorthIt = getenv("RTAMD_BOUNDS_WORTH") ? atof(getenv("RTAMD_BOUNDS_WORTH")) : 1.0;  // (diagnostic override)
+        // (1.0 would be break-even for the rays that start at the camera; measured on one GPU: 0.75 and 1.0 beat 2.0 by 5 % on
+        // cover.yaml, whose cubes then get records over clusters of 2 to 11, 0.75 beats 1.0 by 5 % on the tables scene, and
+        // the other scenes do not care; 0 -- a record at every node -- 1.25 and more lose)
+        // A frame with fewer groups of pixels than the GPU has wave slots waits for its longest chain of dependent rays, and
+        // those rays live among the objects: they meet the boxes, and a record they meet is one more step in the chain.
+        // Records then have to save more to be worth a place (reflect_refract 400x200: 0.39 -> 0.35 ms, as with none at all;
+        // a mesh without records is 2.7 times slower).
+        const bool small_frame = (int64_t)((C.hsize + 7) / 8) * ((C.vsize + 7) / 8) <= (int64_t)16 * ctx->num_cus;
+        const double kWorthIt = getenv("RTAMD_BOUNDS_WORTH") ? atof(getenv("RTAMD_BOUNDS_WORTH")) : small_frame ? 6.0 : 0.75;  // (diagnostic override)
         auto outside = [&](const DVisit& B) {
             double r[4];
             if (!screen_rect(B.w2o, r)) return 0.0;
