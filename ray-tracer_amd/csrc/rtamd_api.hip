@@ -737,6 +737,12 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], b[k]), hi[k] = std::max(hi[k], b[3 + k]);
             }
             for (int k = 0; k < 3; k++) B.w2o[k] = lo[k], B.w2o[3 + k] = hi[k];
+            // the same box as centre and half extent (what the kernel tests: three fused operations per axis), rounded outwards
+            for (int k = 0; k < 3; k++) {
+                const double c = 0.5 * lo[k] + 0.5 * hi[k];
+                B.w2o[6 + k] = c;
+                B.w2o[9 + k] = std::max(c - lo[k], hi[k] - c) * (1.0 + 0x1p-48) + 0x1p-1000;
+            }
             B.kind_flags = DVISIT_BOUNDS;
             if (!dirs.empty()) {
                 B.kind_flags |= DBOUNDS_HAS_CONE << 8;
