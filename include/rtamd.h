@@ -231,7 +231,9 @@ int rtamd_render_rows_static(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, d
 
 /* Camera::render for the whole frame into host memory (either pointer may be NULL). Blocking.
  * The device-side frame is kept by the context between calls; the copy back runs at the rate of the
- * PCIe link when the destination came from rtamd_host_alloc, and through the driver's staging otherwise. */
+ * PCIe link when the destination came from rtamd_host_alloc, and through the driver's staging otherwise.
+ * A frame of 1.5 M pixels or more is rendered as four chunks of rows on a stream of the context's own, each copied
+ * to the host while the chunks after it render (same pixels; rtamd_stats.kernel_ms then spans all the chunks). */
 int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8);
 
 /* Page-locked host memory for the frame: what Canvas::new's Vec<Color> (src/tuple.rs:315-321) becomes when

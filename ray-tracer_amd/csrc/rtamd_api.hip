@@ -47,12 +47,23 @@ struct rtamd_ctx {
     // both reflective and transparent -- each hit on one owes two children, so its pixels run the longest
     // chains of dependent rays.  Their groups go to the front of the work queue.
     std::vector<std::array<int, 4>> costly;
-    int32_t* d_order = nullptr;  // queue position -> group of 64 pixels, for the partition of the frame in order_key
-    size_t order_cap = 0;
-    std::array<int64_t, 8> order_key{{-1, -1, -1, -1, -1, -1, -1, -1}};
-    size_t order_hot = 0, order_len = 0;  // groups the table puts first; its entries
-    int order_teams = 1;                  // lanes per pixel in the groups it marks
-    bool order_used = false;
+    // queue position -> group of 64 pixels, one table per partition of the frame that has been rendered (a few are kept:
+    // the parts a multi-GPU rank holds, the chunks rtamd_render cuts a large frame into)
+    struct OrderTable {
+        int32_t* d = nullptr;
+        size_t cap = 0;
+        std::array<int64_t, 8> key{{-1, -1, -1, -1, -1, -1, -1, -1}};
+        size_t hot = 0, len = 0;  // groups the table puts first; its entries
+        int teams = 1;            // lanes per pixel in the groups it marks
+        bool used = false;
+    };
+    static constexpr int kOrderTables = 8;
+    OrderTable orders[kOrderTables];
+    int order_next = 0;  // the slot the next new partition takes
+    // rtamd_render with a large frame: rendered in chunks of rows whose copies to the host overlap the chunks after them
+    hipStream_t s_render = nullptr, s_copy = nullptr;
+    hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool skip_ev0 = false, skip_ev1 = false;  // (launches between the first and the last chunk leave the timing events alone)
     // device-side frame of rtamd_render (host destination), kept between calls
     double* d_out = nullptr;
     uint8_t* d_out8 = nullptr;
@@ -176,7 +187,12 @@ void rtamd_ctx_destroy(rtamd_ctx* ctx) {
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_frames) (void)hipFree(ctx->d_frames);
-    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    for (auto& t : ctx->orders)
+        if (t.d) (void)hipFree(t.d);
+    if (ctx->s_render) (void)hipStreamDestroy(ctx->s_render);
+    if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+    for (auto& e : ctx->ev_chunk)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_out8) (void)hipFree(ctx->d_out8);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -914,7 +930,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     if ((rc = ensure_frames(ctx, std::max(1, s->max_remaining)))) return rc;
     // ---- where on the screen the costly leaves are (empty list: no preference)
     ctx->costly.clear();
-    ctx->order_key = {{-1, -1, -1, -1, -1, -1, -1, -1}};
+    for (auto& t : ctx->orders) t.key = {{-1, -1, -1, -1, -1, -1, -1, -1}}, t.used = false;
     {
         bool usable = cam_ok;
         for (int i = 0; usable && i < s->n_leaves; i++) {
@@ -1059,8 +1075,14 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
         // Groups that touch a costly rectangle go first, the rest after them, each set in the strided order.
         // The table depends on the partition of the frame only: it is kept until that changes.
         const std::array<int64_t, 8> key{{w.hsize, w.vsize, w.tile_rows, w.part, w.n_parts, w.span, teams_rule ? teams : 1, teams_rule == 1 ? wave_slots : 0}};
-        if (key != ctx->order_key) {
-            ctx->order_used = false;
+        rtamd_ctx::OrderTable* found = nullptr;
+        for (auto& t : ctx->orders)
+            if (t.key == key) found = &t;
+        const bool build = found == nullptr;
+        if (build) found = &ctx->orders[ctx->order_next], ctx->order_next = (ctx->order_next + 1) % rtamd_ctx::kOrderTables;
+        rtamd_ctx::OrderTable& T = *found;
+        if (build) {
+            T.used = false;
             std::vector<int32_t> first, rest;
             first.reserve((size_t)w.n_groups), rest.reserve((size_t)w.n_groups);
             for (int64_t j = 0; j < w.n_groups; j++) {
@@ -1085,9 +1107,9 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
             if (!first.empty() && w.n_groups < ((int64_t)1 << 29)) {
                 // the groups a kernel may give a team of lanes per pixel: marked in the sign bit; with teams such a group
                 // is handed out in `team` pieces (bits 29-30), one per queue entry, so that its pixels spread over as many waves
-                ctx->order_hot = first.size();
+                T.hot = first.size();
                 if (teams_rule == 0 || (teams_rule == 1 && w.n_groups + (int64_t)first.size() * (teams - 1) > wave_slots)) teams = 1;
-                ctx->order_teams = teams;
+                T.teams = teams;
                 if (teams > 1) {
                     std::vector<int32_t> pieces;
                     pieces.reserve(first.size() * (size_t)teams);
@@ -1096,36 +1118,36 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
                     first.swap(pieces);
                 }
                 first.insert(first.end(), rest.begin(), rest.end());
-                if (first.size() > ctx->order_cap) {
+                if (first.size() > T.cap) {
                     HIPCHK(ctx, hipDeviceSynchronize());
-                    if (ctx->d_order) HIPCHK(ctx, hipFree(ctx->d_order));
-                    ctx->d_order = nullptr, ctx->order_cap = 0;
-                    HIPCHK(ctx, hipMalloc(&ctx->d_order, first.size() * sizeof(int32_t)));
-                    ctx->order_cap = first.size();
+                    if (T.d) HIPCHK(ctx, hipFree(T.d));
+                    T.d = nullptr, T.cap = 0;
+                    HIPCHK(ctx, hipMalloc(&T.d, first.size() * sizeof(int32_t)));
+                    T.cap = first.size();
                 }
                 if (getenv("RTAMD_UPLOAD_DUMP")) {  // diagnostic
-                    fprintf(stderr, "[rtamd order] groups %lld hot %zu teams %d entries %zu:", (long long)w.n_groups, ctx->order_hot, teams, first.size());
+                    fprintf(stderr, "[rtamd order] groups %lld hot %zu teams %d entries %zu:", (long long)w.n_groups, T.hot, teams, first.size());
                     for (size_t q = 0; q < std::min<size_t>(first.size(), 40); q++) fprintf(stderr, " %08x", (unsigned)first[q]);
                     fprintf(stderr, "\n");
                 }
                 HIPCHK(ctx, hipDeviceSynchronize());  // an earlier launch may still read the table
-                HIPCHK(ctx, hipMemcpy(ctx->d_order, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-                ctx->order_used = true;
-                ctx->order_len = first.size();
+                HIPCHK(ctx, hipMemcpy(T.d, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                T.used = true;
+                T.len = first.size();
             }
-            ctx->order_key = key;
+            T.key = key;
         }
-        if (ctx->order_used) w.order = ctx->d_order, w.n_queue = (int64_t)ctx->order_len, w.team = ctx->order_teams;
+        if (T.used) w.order = T.d, w.n_queue = (int64_t)T.len, w.team = T.teams;
     }
     if (w.team > 1)  // (pieces of groups are units of work like groups: a wave each)
         blocks = (int)std::min<int64_t>(ctx->max_blocks[2][variant & 63], (w.n_queue + 3) / 4);
     HIPCHK(ctx, hipMemsetAsync(w.queue_head, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
-    HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    if (!ctx->skip_ev0) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, variant, blocks, stream)
                    : w.team > 1              ? rtamd_launch_teams(ctx->ds, w, variant & 63, blocks, stream)
                                              : rtamd_launch_fast(ctx->ds, w, variant, blocks, stream);
     if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+    if (!ctx->skip_ev1) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
     return RTAMD_OK;
 }
@@ -1176,13 +1198,49 @@ int rtamd_render(rtamd_ctx* ctx, int mode, double* h_rgb, uint8_t* h_rgb8) {
     }
     double* d_rgb = h_rgb ? ctx->d_out : nullptr;
     uint8_t* d_u8 = h_rgb8 ? ctx->d_out8 : nullptr;
-    rtamd_rows all{ctx->ds.cam.vsize, 0, 1, 1};
-    int rc = rtamd_render_rows(ctx, &all, mode, d_rgb, d_u8, nullptr);
-    if (rc == RTAMD_OK) {
-        hipError_t e = hipDeviceSynchronize();
-        if (e == hipSuccess && h_rgb) e = hipMemcpy(h_rgb, d_rgb, npx * 3 * sizeof(double), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && h_rgb8) e = hipMemcpy(h_rgb8, d_u8, npx * 3, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(ctx, RTAMD_E_HIP, std::string("render: ") + hipGetErrorString(e));
+    int rc = RTAMD_OK;
+    const int64_t hsize = ctx->ds.cam.hsize, vsize = ctx->ds.cam.vsize;
+    // A large frame takes longer to reach the host than to render (199 MB at 3840x2160: 3.5 ms into page-locked memory,
+    // 1.5 ms of kernel).  It is rendered as a few chunks of rows, all launched at once on one stream; each chunk is
+    // copied on a second stream as soon as it is complete, while the chunks after it render.
+    int64_t chunk_rows = vsize;
+    if ((h_rgb || h_rgb8) && npx >= ((size_t)3 << 19) && !getenv("RTAMD_RENDER_WHOLE")) chunk_rows = ((vsize + 3) / 4 + 7) / 8 * 8;
+    const int n_chunks = (int)((vsize + chunk_rows - 1) / chunk_rows);
+    if (n_chunks <= 1) {
+        rtamd_rows all{ctx->ds.cam.vsize, 0, 1, 1};
+        rc = rtamd_render_rows(ctx, &all, mode, d_rgb, d_u8, nullptr);
+        if (rc == RTAMD_OK) {
+            hipError_t e = hipDeviceSynchronize();
+            if (e == hipSuccess && h_rgb) e = hipMemcpy(h_rgb, d_rgb, npx * 3 * sizeof(double), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && h_rgb8) e = hipMemcpy(h_rgb8, d_u8, npx * 3, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(ctx, RTAMD_E_HIP, std::string("render: ") + hipGetErrorString(e));
+        }
+    } else {
+        if (!ctx->s_render) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_render, hipStreamNonBlocking));
+        if (!ctx->s_copy) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+        for (auto& e : ctx->ev_chunk)
+            if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(ctx, hipDeviceSynchronize());  // (work of earlier calls on other streams)
+        for (int i = 0; i < n_chunks && rc == RTAMD_OK; i++) {
+            const size_t first_px = (size_t)i * (size_t)chunk_rows * (size_t)hsize;
+            rtamd_rows rows{(int32_t)chunk_rows, i, n_chunks, 1};  // (tiles of chunk_rows rows, one tile per part)
+            ctx->skip_ev0 = i != 0, ctx->skip_ev1 = i != n_chunks - 1;  // the timing events span all the chunks
+            rc = rtamd_render_rows(ctx, &rows, mode, d_rgb ? d_rgb + first_px * 3 : nullptr, d_u8 ? d_u8 + first_px * 3 : nullptr, ctx->s_render);
+            ctx->skip_ev0 = ctx->skip_ev1 = false;
+            if (rc == RTAMD_OK) HIPCHK(ctx, hipEventRecord(ctx->ev_chunk[i], ctx->s_render));
+        }
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < n_chunks && rc == RTAMD_OK && e == hipSuccess; i++) {
+            const size_t first_px = (size_t)i * (size_t)chunk_rows * (size_t)hsize;
+            const size_t n_px = (size_t)std::min<int64_t>(chunk_rows, vsize - (int64_t)i * chunk_rows) * (size_t)hsize;
+            e = hipStreamWaitEvent(ctx->s_copy, ctx->ev_chunk[i], 0);
+            if (e == hipSuccess && h_rgb) e = hipMemcpyAsync(h_rgb + first_px * 3, d_rgb + first_px * 3, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->s_copy);
+            if (e == hipSuccess && h_rgb8) e = hipMemcpyAsync(h_rgb8 + first_px * 3, d_u8 + first_px * 3, n_px * 3, hipMemcpyDeviceToHost, ctx->s_copy);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->s_render);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->s_copy);
+        if (rc == RTAMD_OK && e != hipSuccess) rc = fail(ctx, RTAMD_E_HIP, std::string("render: ") + hipGetErrorString(e));
+        if (rc != RTAMD_OK) (void)hipDeviceSynchronize();
     }
     if (rc == RTAMD_OK) {
         // the counter is cumulative (rtamd_reset_stats, rtamd_scene_upload clear it): only what has been added

@@ -88,3 +88,27 @@ def test_teapot_room_quarter_frame(rt, oracle, gpu_ctx):
     ref, _, _ = oracle.OracleScene(sg_path("teapot_room")).render_pixels(pix, w, h, threads=8)
     got = buf[:, torch.from_numpy(xs).cuda()].reshape(-1, 3).cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-8
+
+
+@pytest.mark.parametrize("name,w,h", [("cover", 3840, 2160), ("tables", 2001, 1003), ("glass_spheres", 1600, 1001)])
+def test_host_frame_in_chunks_equals_the_frame_rendered_whole(rt, gpu_ctx, name, w, h):
+    """rtamd_render cuts a large frame into chunks of rows whose copies to the host overlap the chunks after them
+    (Camera::render's Canvas, src/scene.rs:236-248, is the whole frame either way): same bits as one launch into device
+    memory, in both arithmetic modes, float and 8-bit, ordinary and page-locked host memory, one primary ray per pixel."""
+    import torch
+    gpu_ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(w, h).flatten())
+    for mode in (rt.MODE_FAST, rt.MODE_STRICT):
+        d64 = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+        d8 = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+        gpu_ctx.render_rows(8, 0, 1, mode, d_rgb=d64.data_ptr(), d_rgb8=d8.data_ptr())
+        torch.cuda.synchronize()
+        want, want8 = d64.cpu().numpy(), d8.cpu().numpy()
+        for pinned in (False, True):
+            gpu_ctx.reset_stats()
+            rgb, u8 = gpu_ctx.render(w, h, mode, want_u8=True, pinned=pinned)
+            st = gpu_ctx.stats()
+            assert np.array_equal(rgb, want) and np.array_equal(u8, want8), (mode, pinned)
+            assert st.primary_rays == w * h and st.kernel_ms > 0
+        only8 = np.empty((h, w, 3), dtype=np.uint8)  # 8-bit channels alone
+        gpu_ctx._chk(rt._gpu.rtamd_render(gpu_ctx._h, mode, None, only8.ctypes.data))
+        assert np.array_equal(only8, want8)
