@@ -41,6 +41,12 @@ def pytest_sessionstart(session):
             CLI_RUNS[key] = subprocess.run([cli] + args, cwd=d, capture_output=True, text=True, timeout=120)
         except Exception as e:  # the test reports it
             CLI_RUNS[key] = e
+    # the host in plain C (examples/render_c.c): one GPU, then the same GPU three times as the ranks of rtamd_multi_*
+    try:
+        CLI_RUNS["render_c"] = subprocess.run([os.path.join(ROOT, "ray-tracer_amd", "bin", "render_c"), "400", "225", "0", "0", "0"], cwd=d,
+                                              capture_output=True, text=True, timeout=120)
+    except Exception as e:
+        CLI_RUNS["render_c"] = e
 
 
 def _built():

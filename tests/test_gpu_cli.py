@@ -38,3 +38,16 @@ def test_cli_flags_override_size_mode_and_format(rt):
     rgb, _ = rt.Scene.from_yaml(conftest.CLI_RUNS["yaml"]).set_resolution(96, 64).render(rt.MODE_STRICT)
     assert text == rt.canvas_to_ppm(rgb)
     assert text.startswith("P3\n96 64\n255\n") and max(len(ln) for ln in text.splitlines()) <= 70  # src/tuple.rs:343-371
+
+
+def test_host_in_plain_c_renders_on_one_gpu_and_on_a_list_of_gpus():
+    """examples/render_c.c: a scene laid out by hand in the structs of include/rtamd.h, rtamd_render and rtamd_multi_render
+    called from C99 -- the frames must agree to the bit (the program's exit status says so) and show the scene."""
+    r = _run("render_c")
+    out = r.stdout.splitlines()
+    assert out[0].startswith("one GPU: 400x225, ") and " rays, kernel " in out[0]
+    rays = int(out[0].split(", ")[1].split()[0])
+    assert rays > 3 * 400 * 225  # every pixel sees the floor or a ball: a shadow ray each, reflections on top
+    centre = [float(v) for v in out[0].split("centre pixel ")[1].split()]
+    assert all(0.0 < c < 1.5 for c in centre)
+    assert out[1].startswith("3 ranks: largest difference from the one-GPU frame 0 ")

@@ -352,3 +352,18 @@ def test_rows_layout_is_the_rows_rule_as_runs(rt):
             assert rows == rows_mod.part_row_indices(vsize, tile_rows, part, n_parts, span).tolist(), (vsize, tile_rows, part, n_parts, span)
     with pytest.raises(rt.RtamdError):
         rt.rows_layout(10, 8, 2, 2)
+
+
+def test_header_is_plain_c_and_the_c_example_builds(tmp_path):
+    """include/rtamd.h must compile as C99 on its own (bindings in any language start from it), and examples/render_c.c
+    -- a whole host in C -- against it, warnings as errors."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "rtamd.h"\nint main(void) { rtamd_scene s; rtamd_stats t; rtamd_layout l; (void)s, (void)t, (void)l; return (int)sizeof(rtamd_rows) - 16; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(probe)], check=True)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-c", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "render_c.c"), "-o", str(tmp_path / "render_c.o")], check=True)
