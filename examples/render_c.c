@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     for (i = 3; i < argc && n_devices < 16; i++) devices[n_devices++] = atoi(argv[i]);
     if (n_devices == 0) devices[n_devices++] = 0, devices[n_devices++] = 0; /* the same GPU twice: two ranks on one card */
 
-    /* ---- the scene, flat (see INTEGRATION.md for what each table holds) */
+    /* ---- the scene, flat (include/rtamd.h says what each table holds) */
     rtamd_material mats[3];
     rtamd_leaf leaves[3];
     rtamd_visit visits[3];

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box: bench.py over every BASELINE configuration, one JSON line each -> gpurun_out/configs_<tag>.jsonl
+# Runs on the GPU box: bench.py over every benchmark configuration, one JSON line each -> gpurun_out/configs_<tag>.jsonl
 set -euo pipefail
 tag=$1
 out=gpurun_out/configs_$tag.jsonl

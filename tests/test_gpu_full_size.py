@@ -1,4 +1,4 @@
-"""BASELINE-size frames (3840x2160 and 7680x4320) on the GPU.  The oracle cannot render these in the time
+"""Benchmark-size frames (3840x2160 and 7680x4320) on the GPU.  The oracle cannot render these in the time
 of a test, so parity is checked on a lattice of pixels it can, and on properties that do not depend on
 the size: the 8-bit output is the quantisation of the f64 output, a frame rendered in row parts equals
 the frame rendered whole, two renders are identical, and strict and fast arithmetic agree to 1e-8 except
