@@ -3,7 +3,7 @@ CSG objects; patterns, glass, mirrors, one to three lights) rendered small on th
 CPU oracle, compared with the bars of tests/test_gpu_parity.py: STRICT 1e-10, FAST 1e-8 per channel, 8-bit within 1 LSB.
 A ray that grazes an edge or a pattern boundary may land on either side of it in fast arithmetic, so a handful of pixels
 per frame (at most 0.1 %, at least 3) may miss the bars; every frame must be finite, render each pixel once and keep its
-CSG lists within bounds.  As a program it runs a longer campaign: python tests/test_gpu_random_scenes.py [n_scenes] [seed]."""
+CSG lists within bounds.  As a program it runs a longer campaign: python tests/test_gpu_random_scenes.py [n_scenes] [seed] [big]."""
 import os
 import sys
 
@@ -100,10 +100,18 @@ def rand_scene(seed, path):
 
 
 
-def check_scene(rt, oracle, ctx, seed, path):
-    """-> (ok, report line)"""
+def check_scene(rt, oracle, ctx, seed, path, big=False):
+    """-> (ok, report line).  big: the frame at 2048x1152 (the kernels, bounds records and runs of triangles that large
+    frames get), compared on a lattice of its pixels."""
     w, h = rand_scene(seed, path)
-    ref, ref8, _ = oracle.OracleScene(path).render(w, h, threads=8)
+    if big:
+        w, h = 2048, 1152
+        pix = np.arange(seed % 97, w * h, 787)
+        ref, ref8, _ = oracle.OracleScene(path).render_pixels(pix, w, h, threads=8)
+    else:
+        pix = np.arange(w * h)
+        ref, ref8, _ = oracle.OracleScene(path).render(w, h, threads=8)
+        ref, ref8 = ref.reshape(-1, 3), ref8.reshape(-1, 3)
     ctx.upload(rt.Scene.from_sg(path).set_resolution(w, h).flatten())
     line = [f"scene {seed} {w}x{h}:"]
     ok = True
@@ -111,11 +119,12 @@ def check_scene(rt, oracle, ctx, seed, path):
         ctx.reset_stats()
         rgb, u8 = ctx.render(w, h, mode, want_u8=True)
         st = ctx.stats()
-        off = int((np.abs(rgb - ref).max(axis=2) > tol).sum())
-        lsb = np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2)
+        rgb, u8 = rgb.reshape(-1, 3)[pix], u8.reshape(-1, 3)[pix]
+        off = int((np.abs(rgb - ref).max(axis=1) > tol).sum())
+        lsb = np.abs(u8.astype(int) - ref8.astype(int)).max(axis=1)
         far = int((lsb > 1).sum())
         line.append(f"{name} beyond tolerance {off}, 8-bit beyond 1 LSB {far}, overflows {st.csg_overflows};")
-        few = max(3, w * h // 1000)
+        few = max(3, len(pix) // 1000)
         ok = ok and bool(np.isfinite(rgb).all()) and st.primary_rays == w * h and st.csg_overflows == 0 and off <= few and far <= few
     return ok, " ".join(line)
 
@@ -123,6 +132,13 @@ def check_scene(rt, oracle, ctx, seed, path):
 @pytest.mark.parametrize("seed", [100000 + k for k in range(40)])
 def test_random_scene_matches_the_oracle(rt, oracle, gpu_ctx, tmp_path, seed):
     ok, line = check_scene(rt, oracle, gpu_ctx, seed, str(tmp_path / "scene.sg"))
+    print(line)
+    assert ok, line
+
+
+@pytest.mark.parametrize("seed", [300000 + k for k in range(6)])
+def test_random_scene_at_a_large_frame_size(rt, oracle, gpu_ctx, tmp_path, seed):
+    ok, line = check_scene(rt, oracle, gpu_ctx, seed, str(tmp_path / "scene.sg"), big=True)
     print(line)
     assert ok, line
 
@@ -136,6 +152,7 @@ if __name__ == "__main__":
     import oracle_lib
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    big_ = len(sys.argv) > 3 and sys.argv[3] == "big"
     ctx_ = rt_.Context(0)
     tmp = tempfile.mkdtemp(prefix="rtamd_random_")
     bad = 0
@@ -143,7 +160,7 @@ if __name__ == "__main__":
         seed = seed0 * 100000 + k
         path = os.path.join(tmp, f"s{seed}.sg")
         try:
-            ok, line = check_scene(rt_, oracle_lib, ctx_, seed, path)
+            ok, line = check_scene(rt_, oracle_lib, ctx_, seed, path, big_)
         except Exception as e:
             ok, line = False, f"scene {seed}: {type(e).__name__}: {e}"
         print(line + ("" if ok else "   <<<<<< LOOK"), flush=True)
