@@ -137,7 +137,11 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
         g_create_err = "device index out of range";
         return RTAMD_E_INVALID;
     }
-    auto* ctx = new rtamd_ctx();
+    auto* ctx = new (std::nothrow) rtamd_ctx();  // (nothing may unwind across the C boundary)
+    if (!ctx) {
+        g_create_err = "rtamd_ctx_create: out of host memory";
+        return RTAMD_E_LIMIT;
+    }
     ctx->device = device;
     auto bail = [&](const char* what, hipError_t err) {
         g_create_err = std::string(what) + ": " + hipGetErrorString(err);
@@ -1142,13 +1146,16 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
     if (w.team > 1)  // (pieces of groups are units of work like groups: a wave each)
         blocks = (int)std::min<int64_t>(ctx->max_blocks[2][variant & 63], (w.n_queue + 3) / 4);
     HIPCHK(ctx, hipMemsetAsync(w.queue_head, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
-    if (!ctx->skip_ev0) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+    // The static entry point records no timing events: its caller may be capturing the stream into a graph, and an event
+    // recorded during capture can be neither waited for nor read afterwards (kernel_ms then stays 0).
+    const bool time_it = !static_scratch;
+    if (time_it && !ctx->skip_ev0) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, variant, blocks, stream)
                    : w.team > 1              ? rtamd_launch_teams(ctx->ds, w, variant & 63, blocks, stream)
                                              : rtamd_launch_fast(ctx->ds, w, variant, blocks, stream);
     if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    if (!ctx->skip_ev1) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
-    ctx->timed = true;
+    if (time_it && !ctx->skip_ev1) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+    ctx->timed = time_it;
     return RTAMD_OK;
 }
 

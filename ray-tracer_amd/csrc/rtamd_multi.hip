@@ -24,11 +24,12 @@ struct rtamd_multi {
         uint8_t* part8 = nullptr;
         size_t part_cap = 0, part8_cap = 0;
         float render_ms = 0, place_ms = 0;
+        uint64_t ovf_seen = 0;  // CSG list overflows of this rank counted up to the last rtamd_multi_render
     };
     std::vector<Rank> ranks;
     std::string err;
     int hsize = 0, vsize = 0;
-    bool have_scene = false;
+    bool have_scene = false, has_csg = false;
     double* frame = nullptr;  // on ranks[0].device
     uint8_t* frame8 = nullptr;
     size_t frame_cap = 0, frame8_cap = 0;
@@ -154,12 +155,24 @@ int rtamd_multi_upload(rtamd_multi* m, const rtamd_scene* scene) {
     }
     m->hsize = scene->camera.hsize, m->vsize = scene->camera.vsize;
     m->have_scene = true;
+    m->has_csg = scene->n_csg_roots > 0;
+    for (auto& r : m->ranks) r.ovf_seen = 0;  // (rtamd_scene_upload cleared the counters)
     return RTAMD_OK;
+}
+
+// Waits for everything queued on every rank's stream (a failed call may have left work in flight on some of them).
+static void drain(rtamd_multi* m) {
+    for (auto& r : m->ranks) {
+        if (!r.stream) continue;
+        (void)hipSetDevice(r.device);
+        (void)hipStreamSynchronize(r.stream);
+    }
 }
 
 template <class T>
 static int ensure(rtamd_multi* m, int device, T** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return RTAMD_OK;
+    drain(m);  // the frame on the first device is written from the other devices' streams
     MHIP(m, hipSetDevice(device));
     MHIP(m, hipDeviceSynchronize());
     if (*p) MHIP(m, hipFree(*p));
@@ -169,8 +182,18 @@ static int ensure(rtamd_multi* m, int device, T** p, size_t* cap, size_t bytes) 
     return RTAMD_OK;
 }
 
+static int multi_render(rtamd_multi* m, int mode, int tile_rows, int first_parts, int other_parts, double* h_rgb, uint8_t* h_rgb8, int want);
+
 int rtamd_multi_render(rtamd_multi* m, int mode, int tile_rows, int first_parts, int other_parts, double* h_rgb, uint8_t* h_rgb8, int want) {
     if (!m) return RTAMD_E_INVALID;
+    const int rc = multi_render(m, mode, tile_rows, first_parts, other_parts, h_rgb, h_rgb8, want);
+    // A failure part of the way leaves kernels and copies of the ranks queued before it in flight, some of them writing
+    // into the frame on the first device: nothing may outlive the call that the next call could free under it.
+    if (rc != RTAMD_OK) drain(m);
+    return rc;
+}
+
+static int multi_render(rtamd_multi* m, int mode, int tile_rows, int first_parts, int other_parts, double* h_rgb, uint8_t* h_rgb8, int want) {
     if (!m->have_scene) return mfail(m, RTAMD_E_NO_SCENE, "no scene uploaded");
     if (tile_rows < 1 || first_parts < 1 || other_parts < 1) return mfail(m, RTAMD_E_INVALID, "tile_rows and the shares must be positive");
     const bool want64 = h_rgb != nullptr || (want & RTAMD_WANT_F64), want8 = h_rgb8 != nullptr || (want & RTAMD_WANT_U8);
@@ -225,6 +248,19 @@ int rtamd_multi_render(rtamd_multi* m, int mode, int tile_rows, int first_parts,
         MHIP(m, hipEventElapsedTime(&r.render_ms, r.ev[0], r.ev[1]));
         MHIP(m, hipEventElapsedTime(&r.place_ms, r.ev[1], r.ev[2]));
     }
+    // Same pixels as rtamd_render, and the same refusal: a per-lane CSG intersection list that overflowed on any rank
+    // left pixels that mean nothing (the counters are cumulative: what was added since the last look is this frame's).
+    if (m->has_csg) {
+        bool overflowed = false;
+        for (auto& r : m->ranks) {
+            rtamd_stats st;
+            rc = rtamd_get_stats(r.ctx, &st);
+            if (rc != RTAMD_OK) return mfail(m, rc, std::string("device ") + std::to_string(r.device) + ": " + rtamd_last_error(r.ctx));
+            overflowed = overflowed || st.csg_overflows > r.ovf_seen;
+            r.ovf_seen = st.csg_overflows;
+        }
+        if (overflowed) return mfail(m, RTAMD_E_OVERFLOW, "a per-lane CSG intersection list overflowed (RTAMD_CSG_LIST_CAP)");
+    }
     MHIP(m, hipSetDevice(m->ranks[0].device));
     if (h_rgb) MHIP(m, hipMemcpy(h_rgb, m->frame, npx * 3 * sizeof(double), hipMemcpyDeviceToHost));
     if (h_rgb8) MHIP(m, hipMemcpy(h_rgb8, m->frame8, npx * 3, hipMemcpyDeviceToHost));
@@ -266,6 +302,7 @@ int rtamd_multi_reset_stats(rtamd_multi* m) {
     for (auto& r : m->ranks) {
         int rc = rtamd_reset_stats(r.ctx);
         if (rc != RTAMD_OK) return mfail(m, rc, rtamd_last_error(r.ctx));
+        r.ovf_seen = 0;
     }
     return RTAMD_OK;
 }

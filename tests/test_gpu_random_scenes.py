@@ -120,12 +120,21 @@ def check_scene(rt, oracle, ctx, seed, path, big=False):
         rgb, u8 = ctx.render(w, h, mode, want_u8=True)
         st = ctx.stats()
         rgb, u8 = rgb.reshape(-1, 3)[pix], u8.reshape(-1, 3)[pix]
-        off = int((np.abs(rgb - ref).max(axis=1) > tol).sum())
+        diff = np.abs(rgb - ref).max(axis=1)
+        off = int((diff > tol).sum())
         lsb = np.abs(u8.astype(int) - ref8.astype(int)).max(axis=1)
         far = int((lsb > 1).sum())
-        line.append(f"{name} beyond tolerance {off}, 8-bit beyond 1 LSB {far}, overflows {st.csg_overflows};")
+        # A leaf the bounds records skip by mistake, or a slip of the slot-based CSG filter, shows as a handful of pixels
+        # with another object's colour: differences of 1e-2 and more.  STRICT arithmetic may not have a single pixel off by
+        # more than 1e-6 nor beyond 1 LSB; the allowance below is for its pixels between 1e-10 and 1e-6 (ulps of pow,
+        # transforms composed on the host) and for FAST pixels on a knife edge (a tie in t against a real miss).
+        gross = int((diff > 1e-6).sum())
+        where = [f"({int(p % w)},{int(p // w)}: {diff[i]:.2e})" for i, p in enumerate(pix) if diff[i] > tol or lsb[i] > 1][:8]
+        line.append(f"{name} beyond tolerance {off}, beyond 1e-6 {gross}, 8-bit beyond 1 LSB {far}, overflows {st.csg_overflows}{' at ' + ' '.join(where) if where else ''};")
         few = max(3, len(pix) // 1000)
         ok = ok and bool(np.isfinite(rgb).all()) and st.primary_rays == w * h and st.csg_overflows == 0 and off <= few and far <= few
+        if mode == rt.MODE_STRICT:
+            ok = ok and gross == 0 and far == 0
     return ok, " ".join(line)
 
 
