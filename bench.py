@@ -92,6 +92,9 @@ def main():
                     help="with several GPUs: 'equal', 'K0:K' (rank 0 holds K0 interleaved parts of the frame, every other rank K), "
                          "or 'auto': a few such splits are tried during warm-up and the fastest is timed -- rank 0's rows do not "
                          "travel, every other rank's cross one xGMI link")
+    ap.add_argument("--gather", default="f64", choices=["f64", "u8"],
+                    help="what the ranks render and rank 0 assembles: f64 = Canvas.pixels, 24 bytes per pixel (the headline); u8 = the 8-bit "
+                         "channels an image file holds, 3 bytes per pixel -- an eighth of the bytes over every xGMI link")
     ap.add_argument("--brute-force", action="store_true",
                     help="diagnostic: no bounds records, no re-cut of triangle pools, every run of triangles tested for every ray "
                          "(what the reference's World::intersect does), so that the algorithmic roofline fraction is a utilisation")
@@ -137,8 +140,16 @@ def main():
     ctx = ctxs[0]
     W, H, R = a.width, a.height, a.tile_rows
 
+    frame_dtype = torch.float64 if a.gather == "f64" else torch.uint8
+
+    def render_into(c, buf, stream, m=mode):
+        if a.gather == "f64":
+            c.render_rows(R, fg.part, fg.n_parts, m, d_rgb=buf.data_ptr(), stream=stream, span=fg.span)
+        else:
+            c.render_rows(R, fg.part, fg.n_parts, m, d_rgb8=buf.data_ptr(), stream=stream, span=fg.span)
+
     def make_gather(k0, k):
-        g = rows_mod.FrameGather(W, H, R, rank, world, dev, collective=use_dist, shares=rows_mod.shares_for(world, k0, k))
+        g = rows_mod.FrameGather(W, H, R, rank, world, dev, collective=use_dist, shares=rows_mod.shares_for(world, k0, k), dtype=frame_dtype)
         if ctx.part_rows(R, g.part, g.n_parts, g.span) != g.n_rows:
             raise SystemExit("row partition of the library and of rows.py disagree")
         return g
@@ -152,7 +163,7 @@ def main():
             buf = fg.begin()
             if events:
                 events[0].record()  # events bracket the render kernel itself, on the stream it is launched on
-            ctxs[j].render_rows(R, fg.part, fg.n_parts, mode, d_rgb=buf.data_ptr(), stream=streams[j].cuda_stream, span=fg.span)
+            render_into(ctxs[j], buf, streams[j].cuda_stream)
             if events:
                 events[1].record()
             fg.submit()
@@ -202,7 +213,9 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     sts = [c.stats() for c in ctxs]
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    step_kernel_ms = [s.elapsed_time(e) for s, e in ev]  # this rank's render kernel, step by step
+    kernel_ms = float(np.mean(step_kernel_ms))
+    my_kernel_ms = kernel_ms
     counts = torch.tensor([sum(st.primary_rays + st.shadow_rays + st.reflect_rays + st.refract_rays for st in sts),
                            sum(st.shade_points for st in sts), sum(st.light_samples for st in sts),
                            sum(st.container_passes for st in sts)], dtype=torch.float64, device=dev)
@@ -221,7 +234,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         buf = fg.begin()
         e0.record()
-        ctx.render_rows(R, fg.part, fg.n_parts, mode, d_rgb=buf.data_ptr(), stream=cur.cuda_stream, span=fg.span)
+        render_into(ctx, buf, cur.cuda_stream)
         e1.record()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -233,13 +246,19 @@ def main():
     if use_dist:
         dist.all_reduce(phase, op=dist.ReduceOp.MAX)
     render_alone_ms, gather_ms = float(phase[0]), float(phase[1])
+    # per rank, for a run on several GPUs to be readable afterwards: its kernel in the timed steps, its kernel alone, its rows
+    per_rank = torch.tensor([my_kernel_ms, float(np.median(np.array([p[0] for p in [phase.tolist()]]))), float(fg.n_rows)], dtype=torch.float64, device=dev)
+    per_rank_all = [torch.zeros_like(per_rank) for _ in range(world)] if use_dist else [per_rank]
+    if use_dist:
+        dist.all_gather(per_rank_all, per_rank)
+    per_rank_all = [t.tolist() for t in per_rank_all]
     rays, shade_points, light_samples, containers = [float(x) / a.steps for x in counts]
     # One more frame (untimed) with the kernels that count the tests their traversals execute: the timed frames use
     # the kernels without the counters, which cost 5-15 %.  Same scene, same rows, so the counts are those of a timed frame.
-    spare = torch.empty((max(fg.n_rows, 1), W, 3), dtype=torch.float64, device=dev)
+    spare = torch.empty((max(fg.n_rows, 1), W, 3), dtype=frame_dtype, device=dev)
     ctx.reset_stats()
     ctx.count_work(True)
-    ctx.render_rows(R, fg.part, fg.n_parts, mode, d_rgb=spare.data_ptr(), stream=cur.cuda_stream, span=fg.span)
+    render_into(ctx, spare, cur.cuda_stream)
     torch.cuda.synchronize()
     st = ctx.stats()
     ctx.count_work(False)
@@ -255,7 +274,7 @@ def main():
         t = []
         for _ in range(3):
             e0.record()
-            ctx.render_rows(R, fg.part, fg.n_parts, rt.MODE_STRICT, d_rgb=spare.data_ptr(), stream=cur.cuda_stream, span=fg.span)
+            render_into(ctx, spare, cur.cuda_stream, rt.MODE_STRICT)
             e1.record()
             torch.cuda.synchronize()
             t.append(e0.elapsed_time(e1))
@@ -290,6 +309,9 @@ def main():
                        "row_tiles": f"cyclic, {R} rows" + ("" if world == 1 else f"; rank 0 holds {share[0]} of {fg.n_parts} interleaved parts, "
                                                            f"every other rank {share[1]}"),
                        **({"share_trials_ms_per_frame": trials} if trials else {}),
+                       "gather": {"what": "f64 pixels (Canvas.pixels), 24 bytes per pixel" if a.gather == "f64" else "8-bit channels, 3 bytes per pixel",
+                                  "bytes_sent_per_rank_per_frame": fg.sent_bytes, "bytes_per_frame": W * H * 3 * (8 if a.gather == "f64" else 1)},
+                       "per_rank": [{"rank": r, "rows": int(v[2]), "kernel_ms_timed_steps": v[0], "kernel_ms_alone": v[1]} for r, v in enumerate(per_rank_all)],
                        "frames_in_flight": in_flight, **({"rehearsal": "collective path on one rank"} if use_dist and world == 1 else {}),
                        **({"brute_force": "no bounds records, every triangle of every run tested for every ray"} if a.brute_force else {}),
                        **({"strict_arithmetic_kernel_ms": strict_ms} if strict_ms is not None else {})},
@@ -297,24 +319,39 @@ def main():
                        "note": "one frame at a time outside the timed region, slowest rank: render kernel, then gather to rank 0 + de-interleave"},
             "roofline": {"bound": "fp64_valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": achieved / (FP64_VALU_PEAK_TFLOPS * world), "traffic": traffic,
-                         "kernel_ms": kernel_ms, "flops_per_ray": fpr, "algorithmic_flops_per_frame": flops,
+                         "kernel_ms": kernel_ms,
+                         "kernel_ms_steps": {"min": float(np.min(step_kernel_ms)), "median": float(np.median(step_kernel_ms)),
+                                             "max": float(np.max(step_kernel_ms)), "n": len(step_kernel_ms), "of": "rank 0"},
+                         "flops_per_ray": fpr, "algorithmic_flops_per_frame": flops,
                          "executed": executed, "executed_frac": executed / (FP64_VALU_PEAK_TFLOPS * world),
                          "executed_flops_per_frame": executed_flops, "executed_lane_tests_per_frame": lane_tests,
                          "counting_kernel_ms": counting_kernel_ms,
-                         "hbm_algorithmic_bytes_per_frame": W * H * 24,
-                         "hbm_frac": W * H * 24 / (kernel_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
+                         "hbm_algorithmic_bytes_per_frame": W * H * (24 if a.gather == "f64" else 3),
+                         "hbm_frac": W * H * (24 if a.gather == "f64" else 3) / (kernel_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
         }
         if fpr > 100000 or achieved > FP64_VALU_PEAK_TFLOPS * world:
             # the brute-force constant counts leaf tests that the bounds records (triangles, groups of bounded leaves) skip
             out["roofline"]["note"] = ("algorithmic flops count every leaf for every ray; bounds records skip most of those tests here, so frac "
                                        "is not a utilisation: executed_frac (flops of the tests the kernel counted) is, and --brute-force gives the "
                                        "algorithmic figure with nothing skipped")
-        if world == 1 and a.cpu_seconds > 0:
+        if world == 1 and a.cpu_seconds > 0 and a.gather == "f64":
             out["cpu_baseline"], out["parity"] = cpu_baseline(a, sg, frame, rt)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_model():
+    """Model name of the host CPU the baseline ran on (/proc/cpuinfo)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def cpu_baseline(a, sg, frame, rt):
@@ -347,7 +384,8 @@ def cpu_baseline(a, sg, frame, rt):
     base = {"value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
             "sample": f"{pix.size} pixels (every {stride}-th of the {W}x{H} frame), oracle in faithful mode, 1 thread, {dt:.1f} s",
             "rays_reference_equivalent_per_frame": st["rays"] / pix.size * npx,
-            "est_frame_seconds": dt / pix.size * npx, "host_cpus": os.cpu_count(),
+            "est_frame_seconds": dt / pix.size * npx, "host_cpus": os.cpu_count(), "host_cpu_model": cpu_model(),
+            "oracle_build": "g++ -O3 -ffp-contract=off (oracle/Makefile)",
             "cached_mode": {"value": st_c["rays"] / dt_c / 1e6, "unit": "Mrays/s", "est_frame_seconds": dt_c / sub.size * npx,
                             "sample": f"{sub.size} pixels, {dt_c:.1f} s"}}
     parity = {"pixels_checked": int(pix.size), "max_abs_f64": float(np.abs(gpu - rgb).max()),

@@ -151,6 +151,44 @@ _host.rth_free_str.argtypes = [C.c_void_p]
 _host.rth_free_str.restype = None
 _host.rth_obj_info.argtypes = [C.c_char_p] + [C.POINTER(C.c_int)] * 7
 _host.rth_obj_triangle.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+_host.rth_save_png8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+
+
+class Material(C.Structure):
+    """``rth_material`` of include/rtamd_host.h (src/material.rs:8-18 plus the optional Pattern)."""
+    _fields_ = [("color", C.c_double * 3), ("ambient", C.c_double), ("diffuse", C.c_double), ("specular", C.c_double),
+                ("shininess", C.c_double), ("reflective", C.c_double), ("transparency", C.c_double), ("refractive_index", C.c_double),
+                ("pattern", C.c_int32), ("pad_", C.c_int32), ("pat_a", C.c_double * 3), ("pat_b", C.c_double * 3),
+                ("pat_transform", C.c_double * 16)]
+
+
+# every symbol include/rtamd_host.h declares
+HOST_SYMBOLS = ["rth_last_error", "rth_material_default", "rth_world_new", "rth_world_free", "rth_add_sphere", "rth_add_plane", "rth_add_cube",
+                "rth_add_cylinder", "rth_add_cone", "rth_add_triangle", "rth_add_smooth_triangle", "rth_group_begin", "rth_group_end",
+                "rth_csg_begin", "rth_csg_end", "rth_add_light", "rth_set_camera", "rth_world_scene", "rth_load_yaml", "rth_load_yaml_str",
+                "rth_load_sg", "rth_builtin_scene", "rth_save_sg", "rth_free_scene", "rth_scene_info", "rth_set_resolution", "rth_flatten",
+                "rth_flat_view", "rth_free_flat", "rth_render", "rth_canvas_save", "rth_canvas_quantize", "rth_save_png8", "rth_canvas_ppm",
+                "rth_free_str", "rth_obj_info", "rth_obj_triangle"]
+
+_host.rth_material_default.argtypes = [C.POINTER(Material)]
+_host.rth_material_default.restype = None
+_host.rth_world_new.restype = C.c_void_p
+_host.rth_world_free.argtypes = [C.c_void_p]
+_host.rth_world_free.restype = None
+_SHAPE = [C.c_void_p, C.c_void_p, C.POINTER(Material), C.c_int]  # world, transform[16], material, shadow
+for _n in ("rth_add_sphere", "rth_add_plane", "rth_add_cube", "rth_group_begin"):
+    getattr(_host, _n).argtypes = _SHAPE
+_host.rth_add_cylinder.argtypes = _SHAPE + [C.c_double, C.c_double, C.c_int]
+_host.rth_add_cone.argtypes = _SHAPE + [C.c_double, C.c_double, C.c_int]
+_host.rth_add_triangle.argtypes = _SHAPE + [C.c_void_p]
+_host.rth_add_smooth_triangle.argtypes = _SHAPE + [C.c_void_p, C.c_void_p]
+_host.rth_csg_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Material), C.c_int]
+_host.rth_group_end.argtypes = [C.c_void_p]
+_host.rth_csg_end.argtypes = [C.c_void_p]
+_host.rth_add_light.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+_host.rth_set_camera.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+_host.rth_world_scene.argtypes = [C.c_void_p]
+_host.rth_world_scene.restype = C.c_void_p
 
 
 def _host_err():
@@ -223,17 +261,108 @@ class Scene:
             raise _host_err()
         return Flat(h)
 
-    def render(self, mode=MODE_FAST, want_u8=False):
-        """Camera::render on the GPU -> (vsize, hsize, 3) float64 [, uint8], Stats."""
+    def render(self, mode=MODE_FAST, want_u8=False, want_f64=True):
+        """Camera::render on the GPU -> (vsize, hsize, 3) float64 [, uint8], Stats; with ``want_f64=False`` the 8-bit
+        channels alone (3 bytes per pixel over the PCIe link instead of 27) -> uint8, Stats."""
         i = self.info()
-        rgb = np.empty((i["vsize"], i["hsize"], 3), dtype=np.float64)
-        u8 = np.empty((i["vsize"], i["hsize"], 3), dtype=np.uint8) if want_u8 else None
+        rgb = np.empty((i["vsize"], i["hsize"], 3), dtype=np.float64) if want_f64 else None
+        u8 = np.empty((i["vsize"], i["hsize"], 3), dtype=np.uint8) if want_u8 or not want_f64 else None
         st = Stats()
-        if _host.rth_render(self._h, mode, rgb.ctypes.data, u8.ctypes.data if want_u8 else None, C.byref(st)):
+        if _host.rth_render(self._h, mode, rgb.ctypes.data if want_f64 else None, u8.ctypes.data if u8 is not None else None, C.byref(st)):
             raise _host_err()
+        if not want_f64:
+            return u8, st
         return (rgb, u8, st) if want_u8 else (rgb, st)
 
     def __del__(self, _free=_host.rth_free_scene):
+        if getattr(self, "_h", None) and getattr(self, "_borrowed_from", None) is None:  # (a builder's scene is the builder's to free)
+            _free(self._h)
+        self._h = None
+
+
+CSG_OPS = {"union": 0, "intersection": 1, "difference": 2}
+PATTERNS = {"none": 0, "stripe": 1, "gradient": 2, "ring": 3, "checkers": 4, "test": 5}
+
+
+def default_material():
+    m = Material()
+    _host.rth_material_default(C.byref(m))
+    return m
+
+
+def _m16(m):
+    if m is None:
+        return None
+    a = np.ascontiguousarray(m, dtype=np.float64).reshape(16)
+    return a.ctypes.data_as(C.c_void_p), a  # (the array is returned so that it outlives the call)
+
+
+class WorldBuilder:
+    """The scene builder of include/rtamd_host.h: one call per node of the reference's object tree (World.objects,
+    Group.children, Csg.left / right), then ``scene()`` -> the ``Scene`` that flattens and renders like a loaded one."""
+
+    def __init__(self):
+        self._h = _host.rth_world_new()
+        if not self._h:
+            raise _host_err()
+
+    def _chk(self, rc):
+        if rc:
+            raise _host_err()
+        return self
+
+    def _args(self, transform, material, shadow):
+        t = _m16(transform)
+        return (t[0] if t else None), (C.byref(material) if material is not None else None), (1 if shadow else 0), t
+
+    def add(self, kind, transform=None, material=None, shadow=True, mn=None, mx=None, closed=False, points=None, normals=None):
+        t, m, sh, keep = self._args(transform, material, shadow)
+        if kind in ("sphere", "plane", "cube"):
+            return self._chk(getattr(_host, "rth_add_" + kind)(self._h, t, m, sh))
+        if kind in ("cylinder", "cone"):
+            lo = -np.inf if mn is None else mn
+            hi = np.inf if mx is None else mx
+            return self._chk(getattr(_host, "rth_add_" + kind)(self._h, t, m, sh, lo, hi, 1 if closed else 0))
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(12)
+        if kind == "triangle":
+            return self._chk(_host.rth_add_triangle(self._h, t, m, sh, p.ctypes.data))
+        if kind == "smooth_triangle":
+            n = np.ascontiguousarray(normals, dtype=np.float64).reshape(12)
+            return self._chk(_host.rth_add_smooth_triangle(self._h, t, m, sh, p.ctypes.data, n.ctypes.data))
+        raise RtamdError(f"unknown shape kind {kind}")
+
+    def group_begin(self, transform=None, material=None, shadow=True):
+        t, m, sh, keep = self._args(transform, material, shadow)
+        return self._chk(_host.rth_group_begin(self._h, t, m, sh))
+
+    def group_end(self):
+        return self._chk(_host.rth_group_end(self._h))
+
+    def csg_begin(self, op, transform=None, material=None, shadow=True):
+        t, m, sh, keep = self._args(transform, material, shadow)
+        return self._chk(_host.rth_csg_begin(self._h, CSG_OPS[op] if isinstance(op, str) else op, t, m, sh))
+
+    def csg_end(self):
+        return self._chk(_host.rth_csg_end(self._h))
+
+    def light(self, position, intensity=(1, 1, 1)):
+        p, i = np.asarray(position, dtype=np.float64), np.asarray(intensity, dtype=np.float64)
+        return self._chk(_host.rth_add_light(self._h, p.ctypes.data, i.ctypes.data))
+
+    def camera(self, hsize, vsize, fov, transform=None):
+        t = _m16(transform)
+        return self._chk(_host.rth_set_camera(self._h, hsize, vsize, fov, t[0] if t else None))
+
+    def scene(self):
+        """The built World + Camera as a ``Scene`` (borrowed from this builder, which it keeps alive)."""
+        h = _host.rth_world_scene(self._h)
+        if not h:
+            raise _host_err()
+        s = Scene(h)
+        s._borrowed_from = self  # rth_free_scene must not see it
+        return s
+
+    def __del__(self, _free=_host.rth_world_free):
         if getattr(self, "_h", None):
             _free(self._h)
             self._h = None
@@ -284,16 +413,22 @@ class Context:
         fn = _gpu.rtamd_render_rows_static if static else _gpu.rtamd_render_rows
         self._chk(fn(self._h, C.byref(r), mode, C.c_void_p(d_rgb or None), C.c_void_p(d_rgb8 or None), C.c_void_p(stream or None)))
 
-    def render(self, hsize, vsize, mode=MODE_FAST, want_u8=False, pinned=False):
+    def render(self, hsize, vsize, mode=MODE_FAST, want_u8=False, pinned=False, want_f64=True, into=None):
         """Whole frame into host arrays; (hsize, vsize) must be the resolution of the uploaded scene.
-        ``pinned``: the arrays live in page-locked memory from rtamd_host_alloc (freed with the arrays)."""
+        ``pinned``: the arrays live in page-locked memory from rtamd_host_alloc (freed with the arrays);
+        ``want_f64=False``: the 8-bit channels alone; ``into``: (f64 array or None, u8 array or None) to render into."""
         if getattr(self, "_size", None) is not None and self._size != (hsize, vsize):
             raise RtamdError(f"the uploaded scene is {self._size[0]}x{self._size[1]}, not {hsize}x{vsize}")
         new = host_empty if pinned else np.empty
-        rgb = new((vsize, hsize, 3), dtype=np.float64)
-        u8 = new((vsize, hsize, 3), dtype=np.uint8) if want_u8 else None
-        self._chk(_gpu.rtamd_render(self._h, mode, rgb.ctypes.data, u8.ctypes.data if want_u8 else None))
-        return (rgb, u8) if want_u8 else rgb
+        if into is not None:
+            rgb, u8 = into
+        else:
+            rgb = new((vsize, hsize, 3), dtype=np.float64) if want_f64 else None
+            u8 = new((vsize, hsize, 3), dtype=np.uint8) if want_u8 or not want_f64 else None
+        self._chk(_gpu.rtamd_render(self._h, mode, rgb.ctypes.data if rgb is not None else None, u8.ctypes.data if u8 is not None else None))
+        if rgb is None:
+            return u8
+        return (rgb, u8) if (want_u8 or (into is not None and u8 is not None)) else rgb
 
     def color_at(self, rays, remaining, mode=MODE_STRICT):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

@@ -96,3 +96,24 @@ def clone_scene(src):
     d.csg_roots = arr(src.csg_roots, src.n_csg_roots, CsgRoot)
     d.visits = arr(src.visits, src.n_visits, Visit)
     return d, keep
+
+
+def scene_bytes(s):
+    """Every byte an rtamd_scene says, as one dict of byte strings (counts, camera, each array): two scenes that
+    flatten alike compare equal.  Pointers are left out; padding inside the records is included, as upload reads it."""
+    out = {"camera": bytes(s.camera), "counts": repr((s.max_remaining, s.n_lights, s.n_leaves, s.n_chain, s.n_tris, s.n_materials,
+                                                       s.n_csg_nodes, s.n_csg_roots, s.n_visits, s.n_classes)).encode()}
+
+    def arr(name, ptr, n, typ):
+        out[name] = C.string_at(ptr, n * C.sizeof(typ)) if n else b""
+
+    arr("lights", s.lights, s.n_lights, Light)
+    arr("leaves", s.leaves, s.n_leaves, Leaf)
+    arr("chain", s.chain, s.n_chain * 12, C.c_double)
+    arr("tri_geom", s.tri_geom, s.n_tris * 9, C.c_double)
+    arr("tri_normals", s.tri_normals, s.n_tris * 9, C.c_double)
+    arr("materials", s.materials, s.n_materials, Material)
+    arr("csg_nodes", s.csg_nodes, s.n_csg_nodes, CsgNode)
+    arr("csg_roots", s.csg_roots, s.n_csg_roots, CsgRoot)
+    arr("visits", s.visits, s.n_visits, Visit)
+    return out

@@ -437,8 +437,24 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     const bool brute = getenv("RTAMD_BRUTE_FORCE") != nullptr;
     std::vector<double> tri_sorted(s->tri_geom, s->tri_geom + (size_t)s->n_tris * 9);
     std::vector<int32_t> tri_key((size_t)s->n_tris, 0);
-    std::vector<double> run_box(boxes);
-    std::vector<int32_t> run_start((size_t)s->n_leaves, 0), run_count((size_t)s->n_leaves, 0);
+    // A MESH leaf is tested as one run of triangles -- unless it is part of a pool that is cut again below: then the pool's
+    // first leaf stands for all of its runs (as many records as the cut gives, however many leaves the host made), and
+    // the other leaves of the pool get no record of their own.
+    struct Run {
+        int32_t start, count;
+        double box[6];
+    };
+    std::vector<std::vector<Run>> runs_of((size_t)s->n_leaves);  // per leaf: its runs (empty: a pooled leaf that is not the first)
+    // How many triangles the device tests as one run: 64 fill a wave's lanes (one triangle each when few rays come
+    // near), but 48 have tighter boxes, which pays when the frame is large enough to be bound by throughput (teapot room:
+    // 3.87 against 4.03 ms at 3840x2160, 1.41 against 1.44 at 1920x1080); a small frame waits for its longest chain of
+    // rays, and every record more is a step more in it (0.85 against 0.89 ms at 400x200).  Same pixels either way.
+    int run_cap = (long long)s->camera.hsize * (long long)s->camera.vsize >= 2000000 ? 48 : 64;
+    if (const char* e = getenv("RTAMD_MESH_RUN")) run_cap = std::max(1, std::min(64, atoi(e)));  // (diagnostic)
+    // where every plain leaf stands in the host's visit list (a pool's leaves must stand there side by side, in order)
+    std::vector<int32_t> visit_of_leaf((size_t)s->n_leaves, -1);
+    for (int i = 0; i < s->n_visits; i++)
+        if (!(s->visits[i].flags & RTAMD_VISIT_CSG)) visit_of_leaf[(size_t)s->visits[i].unit] = i;
     {
         std::vector<char> in_csg((size_t)s->n_leaves, 0);
         for (int r = 0; r < s->n_csg_roots; r++)
@@ -446,7 +462,11 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         for (int i = 0; i < s->n_leaves; i++) {
             const rtamd_leaf& L = s->leaves[i];
             if (L.kind != RTAMD_MESH) continue;
-            run_start[(size_t)i] = L.tri_start, run_count[(size_t)i] = L.tri_count;
+            {
+                Run r{L.tri_start, L.tri_count, {0, 0, 0, 0, 0, 0}};
+                std::memcpy(r.box, &boxes[(size_t)i * 6], sizeof r.box);
+                runs_of[(size_t)i].push_back(r);
+            }
             for (int k = 0; k < L.tri_count; k++) tri_key[(size_t)L.tri_start + k] = (int32_t)(((uint32_t)i << RTAMD_KEY_SHIFT) | (uint32_t)k);
         }
         const std::vector<int32_t> orig_key(tri_key);
@@ -460,14 +480,15 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             const rtamd_leaf& L = s->leaves[i];
             int j = i + 1;
             if (L.kind == RTAMD_MESH && !in_csg[(size_t)i] && has_box[(size_t)i])
-                while (j < s->n_leaves && same_object(i, j) && s->leaves[j].tri_start == s->leaves[j - 1].tri_start + s->leaves[j - 1].tri_count) j++;
-            if (j - i < 2 || brute) {
+                while (j < s->n_leaves && same_object(i, j) && s->leaves[j].tri_start == s->leaves[j - 1].tri_start + s->leaves[j - 1].tri_count &&
+                       visit_of_leaf[(size_t)i] >= 0 && visit_of_leaf[(size_t)j] == visit_of_leaf[(size_t)i] + (j - i))
+                    j++;
+            const int first = L.tri_start, total = s->leaves[j - 1].tri_start + s->leaves[j - 1].tri_count - first;
+            const int cap = run_cap;
+            if (brute || L.kind != RTAMD_MESH || in_csg[(size_t)i] || !has_box[(size_t)i] || (j - i < 2 && total <= cap)) {
                 i = j;
                 continue;
             }
-            const int first = L.tri_start, total = s->leaves[j - 1].tri_start + s->leaves[j - 1].tri_count - first;
-            int cap = 1;  // triangles per run: what the host chose
-            for (int l = i; l < j; l++) cap = std::max(cap, s->leaves[l].tri_count);
             // object -> world for the corners (as for the boxes above)
             const double* m = L.w2o;
             const double det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
@@ -529,10 +550,6 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 split(b + half, e);
             };
             split(0, total);
-            if ((int)runs.size() > j - i) {  // cannot happen (ceil(total / cap) runs); keep the original runs if it does
-                i = j;
-                continue;
-            }
             if (getenv("RTAMD_UPLOAD_DUMP")) {  // diagnostic
                 auto area = [&](int l, const std::vector<double>& bx) {
                     const double* q = &bx[(size_t)l * 6];
@@ -545,30 +562,28 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                         runs.size(), cap, before);
             }
             int pos = first;
-            for (int l = i; l < j; l++) {
-                const size_t r = (size_t)(l - i);
+            std::vector<Run> cut;
+            for (const auto& rr : runs) {
+                Run r{pos, rr.second - rr.first, {0, 0, 0, 0, 0, 0}};
                 double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                run_start[(size_t)l] = pos, run_count[(size_t)l] = 0;
-                if (r < runs.size()) {
-                    for (int q = runs[r].first; q < runs[r].second; q++, pos++) {
-                        const int t = order[(size_t)q];
-                        std::memcpy(&tri_sorted[(size_t)pos * 9], s->tri_geom + ((size_t)first + t) * 9, 9 * sizeof(double));
-                        tri_key[(size_t)pos] = orig_key[(size_t)first + t];
-                        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], tlo[(size_t)t * 3 + k]), hi[k] = std::max(hi[k], thi[(size_t)t * 3 + k]);
-                    }
-                    run_count[(size_t)l] = runs[r].second - runs[r].first;
+                for (int q = rr.first; q < rr.second; q++, pos++) {
+                    const int t = order[(size_t)q];
+                    std::memcpy(&tri_sorted[(size_t)pos * 9], s->tri_geom + ((size_t)first + t) * 9, 9 * sizeof(double));
+                    tri_key[(size_t)pos] = orig_key[(size_t)first + t];
+                    for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], tlo[(size_t)t * 3 + k]), hi[k] = std::max(hi[k], thi[(size_t)t * 3 + k]);
                 }
-                for (int k = 0; k < 3; k++) {  // (an empty run gets an empty box: lo = inf, hi = -inf)
+                for (int k = 0; k < 3; k++) {
                     const double pad = 1e-6 * std::max({hi[k] - lo[k], std::fabs(lo[k]), std::fabs(hi[k]), 1e-30});
-                    run_box[(size_t)l * 6 + k] = run_count[(size_t)l] ? lo[k] - pad : INFINITY;
-                    run_box[(size_t)l * 6 + 3 + k] = run_count[(size_t)l] ? hi[k] + pad : -INFINITY;
+                    r.box[k] = lo[k] - pad, r.box[3 + k] = hi[k] + pad;
                 }
+                cut.push_back(r);
             }
+            for (int l = i; l < j; l++) runs_of[(size_t)l].clear();
+            runs_of[(size_t)i] = cut;
             if (getenv("RTAMD_UPLOAD_DUMP")) {
                 double after = 0;
-                for (int l = i; l < j; l++) {
-                    const double* q = &run_box[(size_t)l * 6];
-                    const double dx = q[3] - q[0], dy = q[4] - q[1], dz = q[5] - q[2];
+                for (const Run& r : runs_of[(size_t)i]) {
+                    const double dx = r.box[3] - r.box[0], dy = r.box[4] - r.box[1], dz = r.box[5] - r.box[2];
                     after += dx > 0 ? 2 * (dx * dy + dy * dz + dx * dz) : 0.0;
                 }
                 fprintf(stderr, "[rtamd upload]   box area after %.4f\n", after);
@@ -642,7 +657,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if ((rc = upload(ctx, snodes.data(), snodes.size(), &d.csg_slot_nodes))) return rc;
         if ((rc = upload(ctx, slot0.data(), slot0.size(), &d.csg_slot0))) return rc;
     }
-    std::vector<DVisit> dv((size_t)s->n_visits);
+    std::vector<DVisit> dv;
     std::vector<int32_t> class_mat((size_t)std::max(s->n_classes, 1), 0);
     double diag_thr = 0.0;
     // the record of a CSG object: the bounds of all its leaves (no bounds at all when one of them has none, or is a
@@ -656,7 +671,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
         for (int k = 0; k < 3; k++) D.w2o[k] = all ? lo[k] : -INFINITY, D.w2o[3 + k] = all ? hi[k] : INFINITY;
     };
-    auto leaf_record = [&](DVisit& D, int leaf) {
+    auto leaf_record = [&](DVisit& D, int leaf, const Run* run) {  // run: of a MESH leaf, which of its runs the record is for
         const DLeaf& L = dl[leaf];
         std::memcpy(D.w2o, L.w2o, sizeof D.w2o);
         if (L.flags & DLEAF_DIAG) {
@@ -667,28 +682,45 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
         D.p0 = L.p0, D.p1 = L.p1;
         if (L.kind == RTAMD_MESH) {
-            int32_t tr[2] = {run_start[(size_t)leaf], run_count[(size_t)leaf]};  // in tri_sorted / tri_key
+            int32_t tr[2] = {run->start, run->count};  // in tri_sorted / tri_key
             std::memcpy(&D.p0, tr, sizeof tr);
             // the traversal needs the bounds for every run and the matrix only for the runs a ray comes near:
             // the bounds take the matrix's place in the record, the matrix stays in the leaf table
-            std::memcpy(D.w2o, &run_box[(size_t)leaf * 6], 6 * sizeof(double));
+            std::memcpy(D.w2o, run->box, 6 * sizeof(double));
             if (brute)
                 for (int k = 0; k < 3; k++) D.w2o[k] = -INFINITY, D.w2o[3 + k] = INFINITY;
             for (int k = 6; k < 12; k++) D.w2o[k] = 0.0;
         }
         D.kind_flags = (uint32_t)L.kind | (L.flags << 8);
     };
+    dv.clear();
     for (int i = 0; i < s->n_visits; i++) {
         const rtamd_visit& V = s->visits[i];
-        DVisit& D = dv[i];
-        std::memset(&D, 0, sizeof D);
         class_mat[V.eq_class] = V.class_material;
+        DVisit D;
+        std::memset(&D, 0, sizeof D);
         D.unit = V.unit;
         D.vflags_class = (V.flags & 0xffu) | ((uint32_t)V.eq_class << 8);
-        if (V.flags & RTAMD_VISIT_CSG)
+        if (V.flags & RTAMD_VISIT_CSG) {
             csg_record(D, V.unit);
-        else
-            leaf_record(D, V.unit);
+            dv.push_back(D);
+        } else if (dl[(size_t)V.unit].kind != RTAMD_MESH) {
+            leaf_record(D, V.unit, nullptr);
+            dv.push_back(D);
+        } else if (runs_of[(size_t)V.unit].empty()) {
+            // a leaf of a pool other than its first: the pool's records stand at the first leaf's place; what this visit
+            // says about the end of the class goes to the last of them (the pool's visits stand side by side)
+            if ((V.flags & RTAMD_VISIT_CLASS_END) && !dv.empty()) dv.back().vflags_class |= RTAMD_VISIT_CLASS_END;
+        } else {
+            const std::vector<Run>& rs = runs_of[(size_t)V.unit];
+            for (size_t q = 0; q < rs.size(); q++) {
+                DVisit R = D;
+                // (only the last record of a leaf may close the class)
+                if (q + 1 < rs.size()) R.vflags_class &= ~(uint32_t)RTAMD_VISIT_CLASS_END;
+                leaf_record(R, V.unit, &rs[q]);
+                dv.push_back(R);
+            }
+        }
     }
     // the same units once each, in depth-first order (what traversals without a container pass walk)
     std::vector<int> root_of((size_t)s->n_leaves, -1);
@@ -701,7 +733,15 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if (root_of[i] < 0) {
             D.unit = i;
             D.vflags_class = RTAMD_VISIT_FIRST | ((uint32_t)dl[i].eq_class << 8);
-            leaf_record(D, i);
+            if (dl[(size_t)i].kind == RTAMD_MESH) {
+                for (const Run& r : runs_of[(size_t)i]) {  // (none for a pooled leaf that is not the pool's first)
+                    DVisit R = D;
+                    leaf_record(R, i, &r);
+                    dv_dfs.push_back(R);
+                }
+                continue;
+            }
+            leaf_record(D, i, nullptr);
         } else {
             if (i > 0 && root_of[i - 1] == root_of[i]) continue;
             D.unit = root_of[i];

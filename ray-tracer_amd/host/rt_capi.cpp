@@ -2,6 +2,7 @@
 // and the bench). Everything here is a thin wrapper over the C++ API of rt_scene.hpp.
 #include <cstring>
 
+#include "../../include/rtamd_host.h"
 #include "rt_scene.hpp"
 
 namespace rt {
@@ -12,6 +13,7 @@ std::unique_ptr<Scene> builtin_default_world();
 }  // namespace rt
 
 static thread_local std::string g_err;
+void rth_set_error(const std::string& msg) { g_err = msg; }  // (rt_builder.cpp reports through the same string)
 
 template <class F>
 static int guard(F&& f) {
@@ -102,20 +104,24 @@ void* rth_flatten(void* scene, int max_remaining) {
 const rtamd_scene* rth_flat_view(void* flat) { return &((rt::FlatScene*)flat)->view; }
 void rth_free_flat(void* flat) { delete (rt::FlatScene*)flat; }
 
-// Camera::render into caller memory: rgb = hsize*vsize*3 doubles; rgb8 (optional) the 8-bit
-// channels. stats (optional): rtamd_stats of the render.
+// Camera::render into caller memory: rgb = hsize*vsize*3 doubles, rgb8 the 8-bit channels (either may be NULL, not
+// both: with rgb NULL only 3 bytes per pixel leave the device). stats (optional): rtamd_stats of the render.
 int rth_render(void* scene, int mode, double* rgb, uint8_t* rgb8, rtamd_stats* stats) {
     return guard([&] {
         auto* s = (rt::Scene*)scene;
-        if (!s->camera) throw rt::Error("scene has no camera");
+        if (!s || !s->camera) throw rt::Error("scene has no camera");
+        if (!rgb && !rgb8) throw rt::Error("render: neither the f64 pixels nor the 8-bit channels were asked for");
         rt::RenderStats rs;
-        rt::Canvas img = s->camera->render(s->world, mode, &rs);
-        std::memcpy(rgb, (const void*)img.pixels().data(), img.pixels().size() * sizeof(rt::Color));
-        if (rgb8) {
-            auto q = img.to_rgb8();
-            std::memcpy(rgb8, q.data(), q.size());
-        }
+        rt::Canvas img = s->camera->render(s->world, mode, &rs, (rgb ? RTAMD_WANT_F64 : 0) | (rgb8 ? RTAMD_WANT_U8 : 0));
+        if (rgb) std::memcpy(rgb, (const void*)img.pixels().data(), img.pixels().size() * sizeof(rt::Color));
+        if (rgb8) std::memcpy(rgb8, img.rgb8().data(), img.rgb8().size());
         if (stats) *stats = rs.gpu;
+    });
+}
+int rth_save_png8(const uint8_t* rgb8, int w, int h, const char* path) {
+    return guard([&] {
+        if (!rgb8 || w <= 0 || h <= 0 || !path) throw rt::Error("save_png8: bad argument");
+        rt::Canvas::write_png8(path, rgb8, (size_t)w, (size_t)h);
     });
 }
 

@@ -119,6 +119,7 @@ void Canvas::quantize(Color c, uint8_t out[3]) {
     }
 }
 std::vector<uint8_t> Canvas::to_rgb8() const {
+    if (has_u8()) return std::vector<uint8_t>(rgb8_.begin(), rgb8_.end());
     std::vector<uint8_t> out(pixels_.size() * 3);
     for (size_t i = 0; i < pixels_.size(); i++) quantize(pixels_[i], &out[3 * i]);
     return out;
@@ -162,12 +163,16 @@ static void png_chunk(std::ofstream& f, const char* type, const std::vector<uint
     f.write((const char*)c, 4);
 }
 void Canvas::save_png(const std::string& path) const {
-    std::vector<uint8_t> px = to_rgb8();
+    if (has_u8()) return write_png8(path, rgb8_.data(), width_, height_);
+    const std::vector<uint8_t> px = to_rgb8();
+    write_png8(path, px.data(), width_, height_);
+}
+void Canvas::write_png8(const std::string& path, const uint8_t* px, size_t width_, size_t height_) {
     std::vector<uint8_t> raw;
     raw.reserve((width_ * 3 + 1) * height_);
     for (size_t y = 0; y < height_; y++) {
         raw.push_back(0);  // filter: none
-        raw.insert(raw.end(), px.begin() + y * width_ * 3, px.begin() + (y + 1) * width_ * 3);
+        raw.insert(raw.end(), px + y * width_ * 3, px + (y + 1) * width_ * 3);
     }
     uLongf clen = compressBound(raw.size());
     std::vector<uint8_t> z(clen);
@@ -502,11 +507,8 @@ std::unique_ptr<FlatScene> flatten(World& world, const Camera& camera, int max_r
         fs->lights.push_back(d);
     }
     Flattener f(*fs);
-    // Runs of triangles: 64 to a leaf fill a wave's lanes, but 48 have tighter boxes, which pays when the frame is large
-    // enough to be bound by throughput (teapot room: 3.87 against 4.03 ms at 3840x2160, 1.41 against 1.44 at 1920x1080);
-    // a small frame waits for its longest chain of rays, and every record more is a step more in it (0.85 against
-    // 0.89 ms at 400x200).  Same pixels either way.
-    if ((long long)camera.hsize * (long long)camera.vsize >= 2000000) f.mesh_leaf_tris = 48;
+    // (how many triangles the device tests as one run is the device library's choice: rtamd_scene_upload cuts the pools of
+    // triangles again; here consecutive triangles simply fill leaves of kMeshLeafTris)
     if (const char* e = std::getenv("RT_MESH_LEAF")) f.mesh_leaf_tris = std::max(1, std::min(kMeshLeafTris, std::atoi(e)));  // (diagnostic)
     for (auto& o : world.objects) {
         f.visit(*o, Matrix4x4::identity(), nullptr, -1);
@@ -537,7 +539,15 @@ double ms_since(std::chrono::steady_clock::time_point t0) {
 }
 }  // namespace
 
-Canvas Camera::render(World& world, int mode, RenderStats* stats) const {
+Canvas Camera::render(World& world, int mode, RenderStats* stats, int want) const {
+    if (!(want & (RTAMD_WANT_F64 | RTAMD_WANT_U8))) throw Error("render: neither the f64 pixels nor the 8-bit channels were asked for");
+    Canvas image(hsize, vsize, want, false);  // (every pixel is written by the render)
+    render_into(image, world, mode, stats);
+    return image;
+}
+
+void Camera::render_into(Canvas& image, World& world, int mode, RenderStats* stats) const {
+    if (image.width() != hsize || image.height() != vsize) throw Error("render: the canvas is not of the camera's size");
     auto t0 = std::chrono::steady_clock::now();
     auto fs = flatten(world, *this);
     double flatten_ms = ms_since(t0);
@@ -545,18 +555,17 @@ Canvas Camera::render(World& world, int mode, RenderStats* stats) const {
     t0 = std::chrono::steady_clock::now();
     if (rtamd_scene_upload(ctx, &fs->view) != RTAMD_OK) throw Error(std::string("scene upload: ") + rtamd_last_error(ctx));
     double upload_ms = ms_since(t0);
-    Canvas image(hsize, vsize);
     static_assert(sizeof(Color) == 3 * sizeof(double), "Color must be three packed doubles");
-    rtamd_reset_stats(ctx);
+    if (stats) rtamd_reset_stats(ctx);
     t0 = std::chrono::steady_clock::now();
-    int rc = rtamd_render(ctx, mode, reinterpret_cast<double*>(image.pixels().data()), nullptr);
+    int rc = rtamd_render(ctx, mode, image.pixels().empty() ? nullptr : reinterpret_cast<double*>(image.pixels().data()),
+                          image.rgb8().empty() ? nullptr : image.rgb8().data());
     if (rc != RTAMD_OK) throw Error(std::string("render: ") + rtamd_last_error(ctx));
     if (stats) {
         stats->render_ms = ms_since(t0);
         stats->flatten_ms = flatten_ms, stats->upload_ms = upload_ms;
         rtamd_get_stats(ctx, &stats->gpu);
     }
-    return image;
 }
 
 }  // namespace rt

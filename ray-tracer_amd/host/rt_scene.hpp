@@ -5,10 +5,14 @@
 // behind this API -- without the HIP library and a GPU, render() throws.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rtamd.h"
@@ -169,29 +173,88 @@ class Csg : public ShapeT<Csg> {  // src/shapes/csg.rs
     bool shape_eq(const Shape& other) const override;
 };
 
+// Host memory for pixels: page-locked (rtamd_host_alloc) where the GPU library can give such memory, so that a frame
+// arrives at the rate of the PCIe link; ordinary memory on a machine without a GPU (file conversions, tests).
+template <class T>
+class HostBuf {
+   public:
+    HostBuf() = default;
+    HostBuf(size_t n, bool zeroed) : n_(n) {
+        if (!n) return;
+        p_ = static_cast<T*>(rtamd_host_alloc(n * sizeof(T)));
+        pinned_ = p_ != nullptr;
+        if (!p_) p_ = static_cast<T*>(std::malloc(n * sizeof(T)));
+        if (!p_) throw std::bad_alloc();
+        if (zeroed) std::memset(static_cast<void*>(p_), 0, n * sizeof(T));
+    }
+    HostBuf(const HostBuf& o) : HostBuf(o.n_, false) {
+        if (n_) std::memcpy(static_cast<void*>(p_), static_cast<const void*>(o.p_), n_ * sizeof(T));
+    }
+    HostBuf(HostBuf&& o) noexcept : p_(o.p_), n_(o.n_), pinned_(o.pinned_) { o.p_ = nullptr, o.n_ = 0; }
+    HostBuf& operator=(HostBuf o) noexcept {
+        std::swap(p_, o.p_), std::swap(n_, o.n_), std::swap(pinned_, o.pinned_);
+        return *this;
+    }
+    ~HostBuf() {
+        if (p_ && pinned_) rtamd_host_free(p_);
+        if (p_ && !pinned_) std::free(p_);
+    }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    bool page_locked() const { return pinned_; }
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+    const T& at(size_t i) const {
+        if (i >= n_) throw std::out_of_range("pixel index out of range");
+        return p_[i];
+    }
+    T* begin() { return p_; }
+    T* end() { return p_ + n_; }
+    const T* begin() const { return p_; }
+    const T* end() const { return p_ + n_; }
+
+   private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+    bool pinned_ = false;
+};
+
 // ---- src/tuple.rs:309-391
+// A canvas holds the f64 pixels (Canvas.pixels), the 8-bit channels the device quantised from them
+// (`From<Color> for (usize, usize, usize)`, src/tuple.rs:226-237 -- all a PNG or PPM file needs: 3 bytes per pixel
+// instead of 24 over the PCIe link), or both: RTAMD_WANT_F64 / RTAMD_WANT_U8.
 class Canvas {
    public:
-    Canvas(size_t width, size_t height) : width_(width), height_(height), pixels_(width * height) {}
+    Canvas(size_t width, size_t height, int want = RTAMD_WANT_F64, bool zeroed = true)
+        : width_(width), height_(height), pixels_((want & RTAMD_WANT_F64) ? width * height : 0, zeroed),
+          rgb8_((want & RTAMD_WANT_U8) ? width * height * 3 : 0, zeroed) {}
     size_t width() const { return width_; }
     size_t height() const { return height_; }
+    bool has_f64() const { return !pixels_.empty() || width_ * height_ == 0; }
+    bool has_u8() const { return !rgb8_.empty(); }
     void write_pixel(size_t x, size_t y, Color c) {
-        if (x >= width_ || y >= height_) return;
+        if (x >= width_ || y >= height_ || pixels_.empty()) return;
         pixels_[x + y * width_] = c;
     }
     Color pixel_at(size_t x, size_t y) const { return pixels_.at(x + y * width_); }
-    std::vector<Color>& pixels() { return pixels_; }
-    const std::vector<Color>& pixels() const { return pixels_; }
+    HostBuf<Color>& pixels() { return pixels_; }
+    const HostBuf<Color>& pixels() const { return pixels_; }
+    HostBuf<uint8_t>& rgb8() { return rgb8_; }
+    const HostBuf<uint8_t>& rgb8() const { return rgb8_; }
     // `From<Color> for (usize, usize, usize)`, src/tuple.rs:226-237
     static void quantize(Color c, uint8_t out[3]);
-    std::vector<uint8_t> to_rgb8() const;
+    std::vector<uint8_t> to_rgb8() const;          // the device's 8-bit channels when the canvas holds them, else quantised here
     std::string to_ppm() const;                    // P3, lines wrapped at 70 columns, :343-371
     void save_png(const std::string& path) const;  // what to_image().save() writes, :373-390
     void save_ppm(const std::string& path) const;
+    static void write_png8(const std::string& path, const uint8_t* rgb8, size_t width, size_t height);
 
    private:
     size_t width_, height_;
-    std::vector<Color> pixels_;
+    HostBuf<Color> pixels_;
+    HostBuf<uint8_t> rgb8_;
 };
 
 struct RenderStats {
@@ -218,8 +281,12 @@ class Camera {
     double pixel_size() const { return pixel_size_; }
     double half_width() const { return half_width_; }
     double half_height() const { return half_height_; }
-    // Camera::render (src/scene.rs:236-248) on the GPU. mode: RTAMD_MODE_*.
-    Canvas render(World& world, int mode = RTAMD_MODE_FAST, RenderStats* stats = nullptr) const;
+    // Camera::render (src/scene.rs:236-248) on the GPU. mode: RTAMD_MODE_*; want: RTAMD_WANT_F64 | RTAMD_WANT_U8, what
+    // the canvas is to hold (a caller that only writes an image file asks for the 8-bit channels alone).
+    Canvas render(World& world, int mode = RTAMD_MODE_FAST, RenderStats* stats = nullptr, int want = RTAMD_WANT_F64) const;
+    // The same into a canvas that exists (of this camera's size; it keeps what it holds: f64, 8-bit or both): a host
+    // that renders frame after frame pins its memory once.
+    void render_into(Canvas& image, World& world, int mode = RTAMD_MODE_FAST, RenderStats* stats = nullptr) const;
 
    private:
     double pixel_size_, half_width_, half_height_;

@@ -56,8 +56,10 @@ class FrameGather:
     ``gather`` is the plain blocking form.
     """
 
-    def __init__(self, hsize, vsize, tile_rows, rank, world, device, collective=None, shares=None):
-        self.rank, self.world = rank, world
+    def __init__(self, hsize, vsize, tile_rows, rank, world, device, collective=None, shares=None, dtype=torch.float64):
+        # dtype: torch.float64 -- Canvas.pixels, 24 bytes per pixel -- or torch.uint8 -- the 8-bit channels an image file
+        # holds (src/tuple.rs:226-237), 3 bytes per pixel: an eighth of the bytes over every link
+        self.rank, self.world, self.dtype = rank, world, dtype
         self.n_parts, self.spans = shares_for(world) if shares is None else shares
         self.part, self.span = self.spans[rank]
         # a single rank needs no exchange; `collective=True` makes it go through the gather all the same (a rehearsal
@@ -69,19 +71,21 @@ class FrameGather:
         self.n_rows = len(self.rows[rank])
         self.sent_rows = max([len(r) for r in self.rows[1:]], default=0) or len(self.rows[0])
         max_rows = max(self.n_rows, self.sent_rows)
-        self._frames = [torch.empty((vsize, hsize, 3), dtype=torch.float64, device=device) if rank == 0 else None for _ in range(2)]
+        self._frames = [torch.empty((vsize, hsize, 3), dtype=dtype, device=device) if rank == 0 else None for _ in range(2)]
         self._pending = [None, None]
         self._cur = 0      # the slot begin() handed out last
         self._newest = 0   # the slot submitted last
         if not self._collective:
             self._locals = self._frames  # a single rank renders straight into the frame
         else:
-            self._locals = [torch.empty((max_rows, hsize, 3), dtype=torch.float64, device=device) for _ in range(2)]
-            self._gathered = [[torch.empty((self.sent_rows, hsize, 3), dtype=torch.float64, device=device) for _ in range(world)]
+            self._locals = [torch.empty((max_rows, hsize, 3), dtype=dtype, device=device) for _ in range(2)]
+            self._gathered = [[torch.empty((self.sent_rows, hsize, 3), dtype=dtype, device=device) for _ in range(world)]
                               if rank == 0 else None for _ in range(2)]
             self._dst = [torch.from_numpy(r).to(device) for r in self.rows] if rank == 0 else None
         self.local = self._locals[0]
         self.frame = self._frames[0]
+        # bytes a rank other than 0 puts on its link per frame (0 for a single rank that does not rehearse the exchange)
+        self.sent_bytes = self.sent_rows * hsize * 3 * torch.empty((), dtype=dtype).element_size() if self._collective else 0
 
     def _complete(self, slot):
         """Waits for the gather of ``slot`` (if one is under way) and, on rank 0, puts the parts into the frame."""

@@ -114,10 +114,11 @@ def cmd_check(a):
             d = np.abs(rgb - ref)
             d8 = np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2)
             exact = (rgb == ref).all(axis=2).mean()
-            ok = np.isfinite(rgb).all() and np.nanmax(d) <= tol and (d8 <= 1).mean() >= 0.999 and st.rays == ost["rays"]
+            traced = st.primary_rays + st.shadow_rays + st.reflect_rays + st.refract_rays  # (st.rays also counts container passes)
+            ok = np.isfinite(rgb).all() and np.nanmax(d) <= tol and (d8 <= 1).mean() >= 0.999 and traced == ost["rays"]
             rc |= 0 if ok else 1
             print(f"{name:20s} {mname:6s} {w}x{h} {'ok ' if ok else 'BAD'} maxabs {np.nanmax(d):.3e} bitexact {100 * exact:7.3f}% u8>1 {100 * (d8 > 1).mean():.4f}% "
-                  f"rays {st.rays} (oracle {ost['rays']}) kernel {st.kernel_ms:.3f} ms oracle {t_or:.1f}s", flush=True)
+                  f"rays {traced} (oracle {ost['rays']}) kernel {st.kernel_ms:.3f} ms oracle {t_or:.1f}s", flush=True)
     return rc
 
 

@@ -41,6 +41,19 @@ def pytest_sessionstart(session):
             CLI_RUNS[key] = subprocess.run([cli] + args, cwd=d, capture_output=True, text=True, timeout=120)
         except Exception as e:  # the test reports it
             CLI_RUNS[key] = e
+    # a 3840x2160 frame: the 8-bit channels alone (what the PNG holds), then Canvas.pixels as well; five more frames each
+    for key, extra in (("4k_u8", []), ("4k_f64", ["--f64"])):
+        try:
+            CLI_RUNS[key] = subprocess.run([cli, path, "--width", "3840", "--height", "2160", "--repeat", "5", "-o", os.path.join(d, key + ".png")] + extra,
+                                           cwd=d, capture_output=True, text=True, timeout=120)
+        except Exception as e:
+            CLI_RUNS[key] = e
+    # a host in plain C that hands its object tree over call by call (examples/build_world_c.c)
+    try:
+        CLI_RUNS["build_world_c"] = subprocess.run([os.path.join(ROOT, "ray-tracer_amd", "bin", "build_world_c"), "100", "50", os.path.join(d, "csg.f64")],
+                                                   cwd=d, capture_output=True, text=True, timeout=120)
+    except Exception as e:
+        CLI_RUNS["build_world_c"] = e
     # the host in plain C (examples/render_c.c): one GPU, then the same GPU three times as the ranks of rtamd_multi_*
     try:
         CLI_RUNS["render_c"] = subprocess.run([os.path.join(ROOT, "ray-tracer_amd", "bin", "render_c"), "400", "225", "0", "0", "0"], cwd=d,

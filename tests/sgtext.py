@@ -138,3 +138,78 @@ def tetrahedron():
     v = np.array([(1, 1, 1), (1, -1, -1), (-1, 1, -1), (-1, -1, 1)], dtype=float) / 3 ** 0.5
     f = [(0, 1, 2), (0, 3, 1), (0, 2, 3), (1, 3, 2)]
     return v, f
+
+
+def replay(path, rt):
+    """Reads a .sg file and makes the calls of include/rtamd_host.h's scene builder that a host walking the same object
+    tree would make (one per node, groups and CSG nodes bracketed by begin / end) -> rt.WorldBuilder."""
+    xfs, mats = {0: np.eye(4)}, {}
+    b = rt.WorldBuilder()
+    lines = []
+    for raw in open(path):
+        t = raw.split("#")[0].split()
+        if t:
+            lines.append(t)
+    assert lines[0][0] == "rtsg"
+    pos = [1]
+
+    def material(tok):
+        m = rt.default_material()
+        v = [float(x) for x in tok[:10]]
+        m.color[:] = v[0:3]
+        m.ambient, m.diffuse, m.specular, m.shininess, m.reflective, m.transparency, m.refractive_index = v[3:10]
+        if tok[10] != "none":
+            m.pattern = rt.PATTERNS[tok[10]]
+            m.pat_a[:] = [float(x) for x in tok[11:14]]
+            m.pat_b[:] = [float(x) for x in tok[14:17]]
+            m.pat_transform[:] = list(xfs[int(tok[17])].ravel())
+        return m
+
+    def node():
+        t = lines[pos[0]]
+        pos[0] += 1
+        assert t[0] == "node" and t[2] == "mat" and t[4] == "xf" and t[6] == "shadow", t
+        kind, mat, xf, shadow, rest = t[1], mats[int(t[3])], xfs[int(t[5])], t[7] != "0", t[8:]
+        if kind in ("sphere", "plane", "cube"):
+            b.add(kind, xf, mat, shadow)
+        elif kind in ("cylinder", "cone"):
+            b.add(kind, xf, mat, shadow, mn=float(rest[0]), mx=float(rest[1]), closed=rest[2] != "0")
+        elif kind == "tri":
+            p = np.array([float(x) for x in rest[:9]]).reshape(3, 3)
+            b.add("triangle", xf, mat, shadow, points=np.hstack([p, np.ones((3, 1))]))
+        elif kind == "stri":
+            p = np.array([float(x) for x in rest[:9]]).reshape(3, 3)
+            n = np.array([float(x) for x in rest[9:21]]).reshape(3, 4)
+            b.add("smooth_triangle", xf, mat, shadow, points=np.hstack([p, np.ones((3, 1))]), normals=n)
+        elif kind == "group":
+            b.group_begin(xf, mat, shadow)
+            for _ in range(int(rest[0])):
+                node()
+            b.group_end()
+        elif kind == "csg":
+            b.csg_begin(rest[0], xf, mat, shadow)
+            node()
+            node()
+            b.csg_end()
+        else:
+            raise AssertionError(kind)
+
+    while pos[0] < len(lines):
+        t = lines[pos[0]]
+        pos[0] += 1
+        if t[0] == "xf":
+            xfs[int(t[1])] = np.array([float(x) for x in t[2:18]]).reshape(4, 4)
+        elif t[0] == "mat":
+            mats[int(t[1])] = material(t[2:])
+        elif t[0] == "camera":
+            b.camera(int(t[1]), int(t[2]), float(t[3]), xfs[int(t[4])])
+        elif t[0] == "light":
+            b.light([float(x) for x in t[1:4]], [float(x) for x in t[4:7]])
+        elif t[0] == "objects":
+            for _ in range(int(t[1])):
+                node()
+        elif t[0] == "end":
+            break
+        else:
+            raise AssertionError(t[0])
+    return b

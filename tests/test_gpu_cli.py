@@ -51,3 +51,33 @@ def test_host_in_plain_c_renders_on_one_gpu_and_on_a_list_of_gpus():
     centre = [float(v) for v in out[0].split("centre pixel ")[1].split()]
     assert all(0.0 < c < 1.5 for c in centre)
     assert out[1].startswith("3 ranks: largest difference from the one-GPU frame 0 ")
+
+
+def test_cli_at_3840x2160_moves_three_bytes_per_pixel_unless_asked_for_more(rt):
+    """An image file needs the 8-bit channels only: the program fetches those alone (25 MB instead of 224 MB over the PCIe
+    link) into page-locked memory.  Same PNG either way; the repeated frames say what a frame costs once the buffers exist."""
+    import re
+    pngs, times = {}, {}
+    for key in ("4k_u8", "4k_f64"):
+        r = _run(key)
+        m = re.search(r"Rendered again in: ([0-9.]+) ms \(median of 5, (\d+) bytes per pixel into (\S+) memory; kernel ([0-9.]+) ms\)", r.stdout)
+        assert m, r.stdout
+        times[key] = (float(m.group(1)), int(m.group(2)), m.group(3), float(m.group(4)))
+        pngs[key] = np.array(Image.open(os.path.join(conftest.CLI_RUNS["dir"], key + ".png")).convert("RGB"))
+        print(key, r.stdout.splitlines()[2:4])
+    assert pngs["4k_u8"].shape == (2160, 3840, 3) and np.array_equal(pngs["4k_u8"], pngs["4k_f64"])
+    u8, _ = rt.Scene.from_yaml(conftest.CLI_RUNS["yaml"]).set_resolution(3840, 2160).render(rt.MODE_FAST, want_f64=False)
+    assert np.array_equal(pngs["4k_u8"], u8)
+    assert times["4k_u8"][1:3] == (3, "page-locked") and times["4k_f64"][1:3] == (24, "page-locked")
+    # generous bounds (shared test machines): flatten + upload + kernel + copy of one 4K frame
+    assert times["4k_u8"][0] < 10.0 and times["4k_f64"][0] < 25.0 and times["4k_u8"][0] < times["4k_f64"][0]
+
+
+def test_host_in_plain_c_builds_its_scene_call_by_call(oracle):
+    """examples/build_world_c.c: the CSG scene handed over through the scene builder of include/rtamd_host.h, flattened by
+    the library, rendered in strict arithmetic: the frame the oracle renders of that scene."""
+    r = _run("build_world_c")
+    assert "flat scene equals the library's own csg scene: yes" in r.stdout and "2 csg nodes in 2 objects" in r.stdout
+    got = np.fromfile(os.path.join(conftest.CLI_RUNS["dir"], "csg.f64"), dtype=np.float64).reshape(50, 100, 3)
+    want = np.load(os.path.join(conftest.GOLDEN, "oracle", "csg_100x50.npy"))
+    assert np.abs(got - want).max() <= 1e-10  # the bar of strict arithmetic (tests/test_gpu_parity.py)

@@ -367,3 +367,54 @@ def test_header_is_plain_c_and_the_c_example_builds(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(probe)], check=True)
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-c", "-I", os.path.join(root, "include"),
                     os.path.join(root, "examples", "render_c.c"), "-o", str(tmp_path / "render_c.o")], check=True)
+
+
+def test_c99_host_builds_the_csg_scene_call_by_call_to_the_bytes_of_the_librarys_own():
+    """examples/build_world_c.c without a GPU ("-": nothing is rendered): the scene it hands over node by node through
+    rth_add_* / rth_csg_begin / rth_csg_end flattens to the bytes of rth_builtin_scene("csg")."""
+    import subprocess
+    exe = os.path.join(ROOT, "ray-tracer_amd", "bin", "build_world_c")
+    r = subprocess.run([exe, "100", "50", "-"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "11 leaves, 6 materials, 2 csg nodes in 2 objects" in r.stdout and "own csg scene: yes" in r.stdout
+
+
+def _rust_structs(text):
+    """{name: [(field, rust type), ...]} of every #[repr(C)] struct of a Rust source."""
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+)\s*\{(.*?)\}", text, re.S):
+        out[m.group(1)] = [(f.group(1), f.group(2).strip()) for f in re.finditer(r"pub (\w+):\s*([^,\n]+),?", m.group(2))]
+    return out
+
+
+def test_rust_ffi_crate_mirrors_the_structs_field_for_field(rt):
+    """rtamd-sys/src/lib.rs cannot be compiled here (no Rust toolchain in the image), so its #[repr(C)] structs are held
+    against the ctypes mirrors the whole test-suite renders through (which upload validation and the GPU tests prove
+    against the C headers): same fields, same order, same types; and every function of both headers is declared."""
+    abi = rt.abi
+    text = open(os.path.join(ROOT, "rtamd-sys", "src", "lib.rs")).read()
+    rust = _rust_structs(text)
+    ctype_of = {"f64": C.c_double, "i32": C.c_int32, "u32": C.c_uint32, "u64": C.c_uint64, "i64": C.c_int64}
+    pairs = {"rtamd_leaf": abi.Leaf, "rtamd_material": abi.Material, "rtamd_csg_node": abi.CsgNode, "rtamd_csg_root": abi.CsgRoot,
+             "rtamd_visit": abi.Visit, "rtamd_camera": abi.Camera, "rtamd_light": abi.Light, "rtamd_scene": abi.SceneStruct,
+             "rtamd_rows": rt.Rows, "rtamd_stats": rt.Stats, "rtamd_layout": rt.Layout, "rth_material": rt.Material}
+    assert set(rust) == set(pairs)
+    for name, cls in pairs.items():
+        fields = rust[name]
+        assert [f for f, _ in fields] == [f for f, _ in cls._fields_], name
+        for (fname, rtype), (_, ctype) in zip(fields, cls._fields_):
+            m = re.fullmatch(r"\[(\w+); (\d+)\]", rtype)
+            if m:
+                assert ctype._length_ == int(m.group(2)) and ctype._type_ is ctype_of[m.group(1)], (name, fname)
+            elif rtype.startswith("*const "):
+                assert issubclass(ctype, C._Pointer), (name, fname)
+                inner = rtype[len("*const "):]
+                assert ctype._type_ is (ctype_of[inner] if inner in ctype_of else pairs[inner]), (name, fname)
+            elif rtype in pairs:
+                assert ctype is pairs[rtype], (name, fname)
+            else:
+                assert ctype is ctype_of[rtype], (name, fname)
+    declared = set(re.findall(r"pub fn (\w+)\(", text))
+    assert declared == set(rt.GPU_SYMBOLS) | set(rt.HOST_SYMBOLS), declared ^ (set(rt.GPU_SYMBOLS) | set(rt.HOST_SYMBOLS))
+    for f in ("Cargo.toml", "build.rs"):
+        assert os.path.exists(os.path.join(ROOT, "rtamd-sys", f))
