@@ -215,6 +215,12 @@ int64_t rtamd_part_rows(const rtamd_ctx* ctx, const rtamd_rows* rows);
  * device the first time a partition of the frame is used (it builds the work-queue order for it). */
 int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream);
 
+/* No counterpart in the reference.  Does ahead of time what the first rtamd_render_rows of a partition of the frame does
+ * on the host and with blocking copies (it builds the order of the work queue for it): nothing is rendered.  A host that
+ * drives several GPUs calls it for every GPU's rows before it queues the first render, so that the renders start together
+ * (rtamd_multi_render does).  Optional: rtamd_render_rows prepares what it finds unprepared. */
+int rtamd_prepare_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode);
+
 /* No counterpart in the reference.  rtamd_render_rows for callers that cannot allocate device memory or wait for the
  * device: code under HIP graph capture, serving loops, harnesses that forbid hipMalloc.  Same arguments, same pixels
  * to the bit.  The work-queue counters and the per-lane stacks of shade-point frames live in a file-scope device
@@ -225,7 +231,9 @@ int rtamd_render_rows(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* 
  * lanes per block in 64 MiB, i.e. any budget in fast arithmetic, up to 5 in strict; beyond that RTAMD_E_LIMIT with
  * the figures in rtamd_last_error.  With fewer blocks than rtamd_render_rows would launch (strict, budget 2..5) it is
  * slower.  All contexts of one GPU share the array: calls that overlap on one GPU race (and so do a call of this and a
- * call of rtamd_render_rows on the same context, which share its counters and timing events). */
+ * call of rtamd_render_rows on the same context, which share its counters).  The call records no timing events (an
+ * event recorded while a stream is being captured can be neither waited for nor read): rtamd_stats.kernel_ms is 0
+ * after it. */
 #define RTAMD_STATIC_SCRATCH_BYTES (((size_t)64 << 20) + 8192)
 int rtamd_render_rows_static(rtamd_ctx* ctx, const rtamd_rows* rows, int mode, double* d_rgb, uint8_t* d_rgb8, void* stream);
 
@@ -286,7 +294,9 @@ int rtamd_multi_upload(rtamd_multi* m, const rtamd_scene* scene);
  * plain cyclic split -- rank 0's rows do not travel, so a larger share for it can pay).  Every rank renders into a
  * buffer on its own GPU and writes its runs of rows into the frame on rank 0's GPU (one strided copy per rank, each
  * over its own link).  The frame is copied to h_rgb / h_rgb8 where those are not NULL; `want` (RTAMD_WANT_*) asks for
- * a frame that stays on the device (rtamd_multi_frame).  Blocking.  Same pixels as rtamd_render, to the bit. */
+ * a frame that stays on the device (rtamd_multi_frame); with h_rgb NULL and only RTAMD_WANT_U8 (or h_rgb8) asked for,
+ * 3 bytes per pixel instead of 24 cross the links.  Blocking.  Same pixels as rtamd_render, to the bit, and the same
+ * refusal: RTAMD_E_OVERFLOW when a per-lane CSG intersection list overflowed on any rank. */
 int rtamd_multi_render(rtamd_multi* m, int mode, int tile_rows, int first_parts, int other_parts, double* h_rgb, uint8_t* h_rgb8, int want);
 
 /* Device pointers (on devices[0]) of the frame the last rtamd_multi_render assembled; NULL for a kind it was not asked for. */

@@ -66,7 +66,7 @@ class Rows(C.Structure):
 
 # every symbol include/rtamd.h declares
 GPU_SYMBOLS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error", "rtamd_scene_upload", "rtamd_part_rows",
-               "rtamd_render_rows", "rtamd_render_rows_static", "rtamd_render", "rtamd_host_alloc", "rtamd_host_free", "rtamd_color_at", "rtamd_get_stats",
+               "rtamd_prepare_rows", "rtamd_render_rows", "rtamd_render_rows_static", "rtamd_render", "rtamd_host_alloc", "rtamd_host_free", "rtamd_color_at", "rtamd_get_stats",
                "rtamd_reset_stats", "rtamd_count_work", "rtamd_rows_layout", "rtamd_multi_create", "rtamd_multi_destroy",
                "rtamd_multi_last_error", "rtamd_multi_upload", "rtamd_multi_render", "rtamd_multi_frame", "rtamd_multi_get_stats",
                "rtamd_multi_reset_stats"]
@@ -83,6 +83,8 @@ _gpu.rtamd_part_rows.argtypes = [C.c_void_p, C.POINTER(Rows)]
 _gpu.rtamd_part_rows.restype = C.c_int64
 _gpu.rtamd_render_rows.argtypes = [C.c_void_p, C.POINTER(Rows), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 _gpu.rtamd_render_rows.restype = C.c_int
+_gpu.rtamd_prepare_rows.argtypes = [C.c_void_p, C.POINTER(Rows), C.c_int]
+_gpu.rtamd_prepare_rows.restype = C.c_int
 _gpu.rtamd_render_rows_static.argtypes = _gpu.rtamd_render_rows.argtypes
 _gpu.rtamd_render_rows_static.restype = C.c_int
 _gpu.rtamd_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -404,6 +406,11 @@ class Context:
     def part_rows(self, tile_rows, part, n_parts, span=1):
         r = Rows(tile_rows, part, n_parts, span)
         return _gpu.rtamd_part_rows(self._h, C.byref(r))
+
+    def prepare_rows(self, tile_rows, part, n_parts, mode, span=1):
+        """rtamd_prepare_rows: the host-side work of the first render of this partition, ahead of time."""
+        r = Rows(tile_rows, part, n_parts, span)
+        self._chk(_gpu.rtamd_prepare_rows(self._h, C.byref(r), mode))
 
     def render_rows(self, tile_rows, part, n_parts, mode, d_rgb=0, d_rgb8=0, stream=0, span=1, static=False):
         """Asynchronous; d_rgb / d_rgb8 are device addresses (e.g. ``tensor.data_ptr()``).  Renders the tiles of

@@ -214,6 +214,13 @@ static int multi_render(rtamd_multi* m, int mode, int tile_rows, int first_parts
         if (want64 && (rc = ensure(m, r.device, &r.part, &r.part_cap, (size_t)nrows[(size_t)i] * px_row * 3 * sizeof(double)))) return rc;
         if (want8 && (rc = ensure(m, r.device, &r.part8, &r.part8_cap, (size_t)nrows[(size_t)i] * px_row * 3))) return rc;
     }
+    // What a rank's first render of a partition does on the host and with blocking copies (the order of its work queue)
+    // is done for every rank before any kernel is queued: the ranks' kernels then start together, in the first frame too.
+    for (int i = 0; i < n; i++) {
+        if (nrows[(size_t)i] == 0) continue;
+        rc = rtamd_prepare_rows(m->ranks[(size_t)i].ctx, &rows[(size_t)i], mode);
+        if (rc != RTAMD_OK) return mfail(m, rc, std::string("device ") + std::to_string(m->ranks[(size_t)i].device) + ": " + rtamd_last_error(m->ranks[(size_t)i].ctx));
+    }
     // queue everything: render, then this rank's rows into their places of the frame, on the rank's own stream
     for (int i = 0; i < n; i++) {
         auto& r = m->ranks[(size_t)i];

@@ -170,6 +170,7 @@ extern "C" {
     pub fn rtamd_last_error(ctx: *const rtamd_ctx) -> *const c_char;
     pub fn rtamd_scene_upload(ctx: *mut rtamd_ctx, scene: *const rtamd_scene) -> c_int;
     pub fn rtamd_part_rows(ctx: *const rtamd_ctx, rows: *const rtamd_rows) -> i64;
+    pub fn rtamd_prepare_rows(ctx: *mut rtamd_ctx, rows: *const rtamd_rows, mode: c_int) -> c_int;
     pub fn rtamd_render_rows(ctx: *mut rtamd_ctx, rows: *const rtamd_rows, mode: c_int, d_rgb: *mut f64, d_rgb8: *mut u8, stream: *mut c_void) -> c_int;
     /// allocates nothing (callers under HIP graph capture, serving loops)
     pub fn rtamd_render_rows_static(ctx: *mut rtamd_ctx, rows: *const rtamd_rows, mode: c_int, d_rgb: *mut f64, d_rgb8: *mut u8, stream: *mut c_void) -> c_int;

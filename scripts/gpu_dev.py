@@ -10,6 +10,8 @@
         small frames against the CPU oracle, both modes (max |diff|, share of bit-identical pixels, 8-bit distance)
     scripts/gpu_dev.py suite  [--out file.json] [--against file.json]
         `time` + `hash` over the benchmark configurations at their full sizes (what a kernel change is judged by)
+    scripts/gpu_dev.py work   scene W H ...
+        tests the traversals execute per ray, by kind (the counting twins of the kernels), and the mix of rays
     scripts/gpu_dev.py host   scene W H
         per-call time of Scene.render into pageable / page-locked host memory, f64 and 8-bit only
 """
@@ -122,6 +124,26 @@ def cmd_check(a):
     return rc
 
 
+def cmd_work(a):
+    """Tests the traversals execute, per ray (the counting twins of the kernels), and the ray mix."""
+    import torch
+    ctx = rt.Context(0)
+    for name, W, H in triples(a.scenes):
+        ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(W, H).flatten())
+        buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+        ctx.reset_stats()
+        ctx.count_work(True)
+        ctx.render_rows(8, 0, 1, rt.MODE_FAST, d_rgb=buf.data_ptr())
+        st = ctx.stats()
+        ctx.count_work(False)
+        rays = st.rays
+        per = {n[6:]: getattr(st, n) / rays for n, _ in st._fields_ if n.startswith("tests_") and getattr(st, n)}
+        print(f"{name} {W}x{H}: {rays / 1e6:.1f} M traversals (primary {st.primary_rays / rays:.2f}, shadow {st.shadow_rays / rays:.2f}, reflect "
+              f"{st.reflect_rays / rays:.2f}, refract {st.refract_rays / rays:.2f}, containers {st.container_passes / rays:.2f}); lane-tests per traversal: "
+              + ", ".join(f"{k} {v:.2f}" for k, v in per.items()), flush=True)
+    return 0
+
+
 def cmd_host(a):
     name, W, H = triples(a.scenes)[0]
     sc = rt.Scene.from_sg(sg_path(name)).set_resolution(W, H)
@@ -155,6 +177,8 @@ def main():
     p.add_argument("scenes", nargs="*")
     p = sub.add_parser("host")
     p.add_argument("scenes", nargs="*")
+    p = sub.add_parser("work")
+    p.add_argument("scenes", nargs="*")
     a = ap.parse_args()
     if a.cmd == "time":
         return cmd_time_hash(a, False)
@@ -164,6 +188,8 @@ def main():
         return cmd_time_hash(a, True, SUITE)
     if a.cmd == "check":
         return cmd_check(a)
+    if a.cmd == "work":
+        return cmd_work(a)
     return cmd_host(a)
 
 

@@ -58,12 +58,14 @@ def test_unequal_shares_tile_the_frame(vsize, tile_rows, world, rank0_parts, oth
         assert abs(len(parts[0]) / vsize - rank0_parts / n_parts) < 0.02
 
 
-@pytest.mark.parametrize("world,w,h,tile_rows,rank0_parts,other_parts",
-                         [(2, 40, 27, 4, 1, 1), (3, 24, 10, 8, 1, 1), (2, 40, 27, 2, 2, 1), (3, 24, 31, 2, 5, 2), (3, 24, 9, 4, 3, 1)])
-def test_frame_gather_over_gloo(oracle, tmp_path, world, w, h, tile_rows, rank0_parts, other_parts):
+@pytest.mark.parametrize("world,w,h,tile_rows,rank0_parts,other_parts,what",
+                         [(2, 40, 27, 4, 1, 1, "f64"), (3, 24, 10, 8, 1, 1, "f64"), (2, 40, 27, 2, 2, 1, "f64"), (3, 24, 31, 2, 5, 2, "f64"),
+                          (3, 24, 9, 4, 3, 1, "f64"), (2, 40, 27, 4, 1, 1, "u8"), (8, 32, 70, 2, 1, 1, "u8"), (8, 32, 70, 2, 2, 1, "f64")])
+def test_frame_gather_over_gloo(oracle, tmp_path, world, w, h, tile_rows, rank0_parts, other_parts, what):
     """world processes each produce their rows; rank 0 must end with exactly the frame a single process
     renders (the second case leaves rank 2 without any row; the later ones give rank 0 a larger share than the
-    others, whose rows alone travel; in the last only rank 0 has rows)."""
+    others, whose rows alone travel; in the fifth only rank 0 has rows; "u8": the 8-bit channels travel, 3 bytes per pixel
+    instead of 24; the last two are the eight ranks of a whole node)."""
     out = str(tmp_path / "frame.npy")
     port = _free_port()
     procs = []
@@ -71,7 +73,7 @@ def test_frame_gather_over_gloo(oracle, tmp_path, world, w, h, tile_rows, rank0_
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(w), str(h),
-                                       str(tile_rows), out, str(rank0_parts), str(other_parts)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                       str(tile_rows), out, str(rank0_parts), str(other_parts), what], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
         try:
@@ -81,5 +83,6 @@ def test_frame_gather_over_gloo(oracle, tmp_path, world, w, h, tile_rows, rank0_
                 q.kill()
             pytest.fail("distributed rehearsal timed out")
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
-    whole, _, _ = oracle.OracleScene(sg_path("cover")).render(w, h)
-    assert np.array_equal(np.load(out), whole)
+    whole, whole8, _ = oracle.OracleScene(sg_path("cover")).render(w, h)
+    got = np.load(out)
+    assert got.dtype == (np.uint8 if what == "u8" else np.float64) and np.array_equal(got, whole8 if what == "u8" else whole)
