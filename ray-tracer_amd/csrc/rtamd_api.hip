@@ -756,7 +756,33 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     // smaller than its parent's and the records below it cost several times the test.  A bounds record
     // carries the union of the bounds below it and the number of records (nested bounds records included) a wave may
     // skip when none of its rays meets them.  A record that closes an equality class is skipped only when it is that whole class.
-    std::vector<double> cone_dirs;
+    // A ray nearly parallel to a cone's side gets an intersection that may lie outside the cone's bounds (see the kernel).
+    // "Nearly parallel" is a quadratic form of the world-space direction d: with M the 3x3 part of the cone's world ->
+    // object matrix, a = (M d)_x^2 - (M d)_y^2 + (M d)_z^2 = d^T Q d, Q = M^T diag(1, -1, 1) M.  The scene's distinct Q
+    // (cones that differ by a turn about their own axis, or point the other way, share one) are numbered; a ray works
+    // its 64-bit set of risky orientations out once per traversal, and a bounds record carries the set of those below it
+    // (orientation k -> bit k % 64).  Per orientation: Qxx, Qyy, Qzz, 2 Qxy, 2 Qxz, 2 Qyz, two spare doubles.
+    std::vector<double> cone_quads;
+    auto cone_bit = [&](const double* m) {
+        const double M[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
+        double Q[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Q[i][j] = M[0][i] * M[0][j] - M[1][i] * M[1][j] + M[2][i] * M[2][j];
+        const double q6[6] = {Q[0][0], Q[1][1], Q[2][2], 2.0 * Q[0][1], 2.0 * Q[0][2], 2.0 * Q[1][2]};
+        double big = 0.0;
+        for (double v : q6) big = std::max(big, std::fabs(v));
+        size_t k = 0;
+        for (; k < cone_quads.size() / 8; k++) {  // (the kernel's margin is 4 EPSILON against the cone test's own EPSILON: 1e-9 is lost in it)
+            bool same = true;
+            for (int i = 0; i < 6; i++) same = same && std::fabs(cone_quads[k * 8 + (size_t)i] - q6[i]) <= 1e-9 * big;
+            if (same) break;
+        }
+        if (k == cone_quads.size() / 8) {
+            cone_quads.insert(cone_quads.end(), q6, q6 + 6);
+            cone_quads.insert(cone_quads.end(), 2, 0.0);
+        }
+        return (uint64_t)1 << (k % 64);
+    };
     auto with_bounds = [&](const std::vector<DVisit>& in) {
         if (brute) return in;
         // A record that closes a class may be skipped only when it is the whole class (the record before it
@@ -774,23 +800,16 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             DVisit B;
             std::memset(&B, 0, sizeof B);
             double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            // the kernel looks closer before it passes over a cone (rtamd_kernel.inc): the distinct orientations of
-            // the cones under this record
-            std::vector<std::array<double, 9>> dirs;
-            auto add_dir = [&](const double* m9) {
-                std::array<double, 9> a;
-                std::copy(m9, m9 + 9, a.begin());
-                if (std::find(dirs.begin(), dirs.end(), a) == dirs.end()) dirs.push_back(a);
-            };
+            // the kernel looks closer before it passes over a cone (rtamd_kernel.inc): which of the scene's cone orientations
+            // (cone_quads, one bit each) lie under this record
+            uint64_t cone_mask = 0;
             for (const DVisit& v : body) {
                 if ((v.kind_flags & 0xffu) == RTAMD_CONE) {
-                    const double* m = dl[(size_t)v.unit].w2o;
-                    const double m9[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
-                    add_dir(m9);
+                    cone_mask |= cone_bit(dl[(size_t)v.unit].w2o);
                 } else if ((v.kind_flags & 0xffu) == DVISIT_BOUNDS && ((v.kind_flags >> 8) & DBOUNDS_HAS_CONE)) {
-                    int32_t sc[2];
-                    std::memcpy(sc, &v.p0, sizeof sc);
-                    for (int q = sc[0]; q < sc[0] + sc[1]; q++) add_dir(&cone_dirs[(size_t)q * 9]);
+                    uint64_t below;
+                    std::memcpy(&below, &v.p0, sizeof below);
+                    cone_mask |= below;
                 }
                 const uint32_t vk = v.kind_flags & 0xffu;  // bounds records and runs of triangles hold their box themselves
                 const double* b = vk == DVISIT_BOUNDS || vk == RTAMD_MESH ? v.w2o : &boxes[(size_t)v.unit * 6];
@@ -804,11 +823,9 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
                 B.w2o[9 + k] = std::max(c - lo[k], hi[k] - c) * (1.0 + 0x1p-48) + 0x1p-1000;
             }
             B.kind_flags = DVISIT_BOUNDS;
-            if (!dirs.empty()) {
+            if (cone_mask != 0) {
                 B.kind_flags |= DBOUNDS_HAS_CONE << 8;
-                const int32_t sc[2] = {(int32_t)(cone_dirs.size() / 9), (int32_t)dirs.size()};
-                std::memcpy(&B.p0, sc, sizeof sc);
-                for (const auto& a : dirs) cone_dirs.insert(cone_dirs.end(), a.begin(), a.end());
+                std::memcpy(&B.p0, &cone_mask, sizeof cone_mask);
             }
             B.unit = (int32_t)body.size();
             return B;
@@ -969,7 +986,12 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     d.n_visits = (int)dv.size() - 1;
     d.n_visits_dfs = (int)dv_dfs.size();
     d.diag_thr = diag_thr;
-    if ((rc = upload(ctx, cone_dirs.data(), cone_dirs.size(), &d.cone_dirs))) return rc;
+    while ((cone_quads.size() / 8) % 4 != 0) {  // the kernel takes four at a time: |d|^2 is never near zero
+        const double never[8] = {1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        cone_quads.insert(cone_quads.end(), never, never + 8);
+    }
+    d.n_cone_quads = (int32_t)(cone_quads.size() / 8);
+    if ((rc = upload(ctx, cone_quads.data(), cone_quads.size(), &d.cone_quads))) return rc;
     dv_dfs.push_back(DVisit{});  // spare record: the loop over a run of cubes reads one record past the run
     if ((rc = upload(ctx, dv_dfs.data(), dv_dfs.size(), &d.visits_dfs))) return rc;
     if ((rc = upload(ctx, class_mat.data(), class_mat.size(), &d.class_material))) return rc;

@@ -55,7 +55,8 @@ struct alignas(16) DVisit {
 
 #define DBOUNDS_HAS_CONE 1u  // leaf flag of a bounds record: a cone is among the records it covers
 #define DVISIT_BOUNDS 6u  // kind of a bounds record: w2o[0..5] = lo xyz, hi xyz (world space); unit = records to skip;
-                          // with DBOUNDS_HAS_CONE the bytes of p0 hold int32 start, count of its list in DScene::cone_dirs
+                          // with DBOUNDS_HAS_CONE the bytes of p0 hold the 64-bit set of the cone orientations below it
+                          // (entry k of DScene::cone_quads -> bit k % 64)
 
 // Small CSG objects (at most RTAMD_CSG_LIST_SMALL possible intersections on a ray) are evaluated without a sorted list:
 // every possible intersection has a fixed slot -- the leaves of the object in depth-first order, each with its 2
@@ -82,6 +83,8 @@ struct DScene {
     int32_t n_leaves;
     int32_t ri_safe;  // every refractive index is finite and > 0
     int32_t n_visits_dfs;
+    int32_t n_cone_quads;  // entries of cone_quads
+    int32_t pad_;
     double diag_thr;  // FAST: smallest |direction component| for which every axis-aligned cube sees |scaled component| >= EPSILON
     const rtamd_light* lights;
     const DLeaf* leaves;
@@ -90,7 +93,7 @@ struct DScene {
     const double* tri_geom;
     const double* tri_sorted;  // the same triangles in the order of the runs the traversal tests (9 doubles each)
     const int32_t* tri_key;    // per triangle of tri_sorted: leaf << RTAMD_KEY_SHIFT | slot of its place in tri_geom
-    const double* cone_dirs;  // 9 doubles each: the 3x3 part of the world -> object matrix of a cone (lists that bounds records point into)
+    const double* cone_quads;  // 8 doubles per distinct cone orientation of the scene: d -> a = Qxx dx^2 + Qyy dy^2 + Qzz dz^2 + 2Qxy dx dy + 2Qxz dx dz + 2Qyz dy dz, two spare
     const double* mesh_box;  // per leaf 6 doubles: enlarged world-space bounds (lo xyz, hi xyz) of a MESH leaf's triangles
     const double* tri_normals;
     const rtamd_material* materials;

@@ -74,7 +74,7 @@ def sections():
         ("auto f64 = [&](int i) {  // i-th double", "general leaf"),
         ("if (cont_mask != 0)", "after traversal: n1/n2"),
         ("what the traversal was for", "hit / prepare_computations"),
-        ("c_shade += __popcll", "shade set-up"),
+        ("PROF_MARK(5);  // colour / container results", "shade set-up"),
         ("const int light_rounds", "lighting"),
         ("PROF_MARK(7);  // lighting", "return / next ray"),
         ("counters: wave -> block", "epilogue"),
