@@ -14,6 +14,13 @@
         tests the traversals execute per ray, by kind (the counting twins of the kernels), and the mix of rays
     scripts/gpu_dev.py host   scene W H
         per-call time of Scene.render into pageable / page-locked host memory, f64 and 8-bit only
+    scripts/gpu_dev.py parts  scene W H
+        kernel time of each rank's part of a frame (what one GPU of 1, 2, 4, 8 renders), one part after the other on one GPU
+    scripts/gpu_dev.py multi  scene W H
+        rtamd_multi_render with the device list naming GPU 0 one to four times: what the split itself costs
+    scripts/gpu_dev.py phase  scene W H
+        three frames per mode; with the -DRTAMD_PROFILE build (RTAMD_LIB_DIR=ray-tracer_amd/lib_prof RTAMD_PROFILE_DUMP=1)
+        the library prints cycles per phase of the main loop for each
 """
 import argparse
 import hashlib
@@ -163,6 +170,60 @@ def cmd_host(a):
     return 0
 
 
+def cmd_parts(a):
+    import torch
+    name, W, H = triples(a.scenes)[0]
+    ctx = rt.Context(0)
+    ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(W, H).flatten())
+    buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+    base = None
+    for n in (1, 2, 4, 8):
+        times = []
+        for p in range(n):
+            best = 1e9
+            for _ in range(4):
+                ctx.reset_stats()
+                ctx.render_rows(8, p, n, rt.MODE_FAST, d_rgb=buf.data_ptr())
+                best = min(best, ctx.stats().kernel_ms)
+            times.append(best)
+        base = base or times[0]
+        print(f"{name} {W}x{H} parts {n}: kernel ms per part " + " ".join(f"{t:.3f}" for t in times) +
+              f"  -> slowest {max(times):.3f}, speed-up over one part {base / max(times):.2f}", flush=True)
+    return 0
+
+
+def cmd_multi(a):
+    name, W, H = triples(a.scenes)[0]
+    flat = rt.Scene.from_sg(sg_path(name)).set_resolution(W, H).flatten()
+    for n in (1, 2, 4):
+        m = rt.MultiContext([0] * n).upload(flat)
+        for k0 in (1, 2):
+            ts = []
+            for _ in range(6):
+                t0 = time.perf_counter()
+                m.render_on_device(rt.MODE_FAST, 8, k0, 1)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            _, r, p = m.stats()
+            print(f"{name} {W}x{H} contexts {n} shares {k0}:1  wall {np.median(ts[1:]):.3f} ms  render/rank {np.round(r, 3)}  place/rank {np.round(p, 3)}", flush=True)
+        m.close()
+    return 0
+
+
+def cmd_phase(a):
+    import torch
+    ctx = rt.Context(0)
+    for name, W, H in triples(a.scenes):
+        ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(W, H).flatten())
+        buf = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+        for mname, mode in MODES.items():
+            for _ in range(3):
+                ctx.reset_stats()
+                ctx.render_rows(8, 0, 1, mode, d_rgb=buf.data_ptr())
+                st = ctx.stats()  # (the profile build prints its phase timers here)
+            print(f"{name} {W}x{H} {mname}: kernel {st.kernel_ms:.3f} ms, rays {st.rays}, containers {st.container_passes}, shade points {st.shade_points}", flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -177,8 +238,9 @@ def main():
     p.add_argument("scenes", nargs="*")
     p = sub.add_parser("host")
     p.add_argument("scenes", nargs="*")
-    p = sub.add_parser("work")
-    p.add_argument("scenes", nargs="*")
+    for c in ("work", "parts", "multi", "phase"):
+        p = sub.add_parser(c)
+        p.add_argument("scenes", nargs="*")
     a = ap.parse_args()
     if a.cmd == "time":
         return cmd_time_hash(a, False)
@@ -188,8 +250,8 @@ def main():
         return cmd_time_hash(a, True, SUITE)
     if a.cmd == "check":
         return cmd_check(a)
-    if a.cmd == "work":
-        return cmd_work(a)
+    if a.cmd in ("work", "parts", "multi", "phase"):
+        return {"work": cmd_work, "parts": cmd_parts, "multi": cmd_multi, "phase": cmd_phase}[a.cmd](a)
     return cmd_host(a)
 
 

@@ -466,6 +466,23 @@ def test_ragged_frame_sizes(rt, oracle, gpu_ctx, w, h):
             assert gpu_ctx.stats().primary_rays == w * h
 
 
+def test_reflect_refract_at_its_declared_size(rt, oracle, gpu_ctx):
+    """The first benchmark configuration as the reference renders it: scenes/reflect_refract.yaml at the 400 x 200 its
+    camera declares, recursion budget 4 -- the whole frame of both arithmetic modes against the oracle's, and the same
+    rays traced.  (At this size the fast frame comes from the kernels with teams of lanes per pixel.)"""
+    w, h = 400, 200
+    ref, ref8, ost = oracle.OracleScene(sg_path("reflect_refract")).render(w, h, threads=8)
+    _upload(rt, gpu_ctx, "reflect_refract", w, h)
+    for mode, (m, tol) in _modes(rt).items():
+        gpu_ctx.reset_stats()
+        rgb, u8 = gpu_ctx.render(w, h, m, want_u8=True)
+        st = gpu_ctx.stats()
+        assert np.isfinite(rgb).all() and np.abs(rgb - ref).max() <= tol, mode
+        assert (np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+        assert st.primary_rays == w * h
+        assert st.primary_rays + st.shadow_rays + st.reflect_rays + st.refract_rays == ost["rays"]
+
+
 EMPTY_CAMERA = """
 - add: camera
   width: 24
