@@ -761,7 +761,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     // object matrix, a = (M d)_x^2 - (M d)_y^2 + (M d)_z^2 = d^T Q d, Q = M^T diag(1, -1, 1) M.  The scene's distinct Q
     // (cones that differ by a turn about their own axis, or point the other way, share one) are numbered; a ray works
     // its 64-bit set of risky orientations out once per traversal, and a bounds record carries the set of those below it
-    // (orientation k -> bit k % 64).  Per orientation: Qxx, Qyy, Qzz, 2 Qxy, 2 Qxz, 2 Qyz, two spare doubles.
+    // (orientation k -> bit k % 64).  Per orientation: Qxx, Qyy, Qzz, 2 Qxy, 2 Qxz, 2 Qyz, the Frobenius norm of Q, one spare double.
     std::vector<double> cone_quads;
     auto cone_bit = [&](const double* m) {
         const double M[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
@@ -779,7 +779,11 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         }
         if (k == cone_quads.size() / 8) {
             cone_quads.insert(cone_quads.end(), q6, q6 + 6);
-            cone_quads.insert(cone_quads.end(), 2, 0.0);
+            double fro = 0.0;  // Frobenius norm of Q (>= its largest eigenvalue), rounded up
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) fro += Q[i][j] * Q[i][j];
+            cone_quads.push_back(std::sqrt(fro) * (1.0 + 1e-9));
+            cone_quads.push_back(0.0);
         }
         return (uint64_t)1 << (k % 64);
     };
@@ -986,10 +990,6 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     d.n_visits = (int)dv.size() - 1;
     d.n_visits_dfs = (int)dv_dfs.size();
     d.diag_thr = diag_thr;
-    while ((cone_quads.size() / 8) % 4 != 0) {  // the kernel takes four at a time: |d|^2 is never near zero
-        const double never[8] = {1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        cone_quads.insert(cone_quads.end(), never, never + 8);
-    }
     d.n_cone_quads = (int32_t)(cone_quads.size() / 8);
     if ((rc = upload(ctx, cone_quads.data(), cone_quads.size(), &d.cone_quads))) return rc;
     dv_dfs.push_back(DVisit{});  // spare record: the loop over a run of cubes reads one record past the run

@@ -93,7 +93,7 @@ struct DScene {
     const double* tri_geom;
     const double* tri_sorted;  // the same triangles in the order of the runs the traversal tests (9 doubles each)
     const int32_t* tri_key;    // per triangle of tri_sorted: leaf << RTAMD_KEY_SHIFT | slot of its place in tri_geom
-    const double* cone_quads;  // 8 doubles per distinct cone orientation of the scene: d -> a = Qxx dx^2 + Qyy dy^2 + Qzz dz^2 + 2Qxy dx dy + 2Qxz dx dz + 2Qyz dy dz, two spare
+    const double* cone_quads;  // 8 doubles per distinct cone orientation of the scene: d -> a = Qxx dx^2 + Qyy dy^2 + Qzz dz^2 + 2Qxy dx dy + 2Qxz dx dz + 2Qyz dy dz, then |Q| (Frobenius) and a spare
     const double* mesh_box;  // per leaf 6 doubles: enlarged world-space bounds (lo xyz, hi xyz) of a MESH leaf's triangles
     const double* tri_normals;
     const rtamd_material* materials;
