@@ -1425,6 +1425,15 @@ int rtamd_get_stats(rtamd_ctx* ctx, rtamd_stats* out) {
         if (p[3] && ctx->stat_blocks > 1 && q[4])
             fprintf(stderr, "[rtamd profile]   traversals with a container pass pending: %llu (%.1f %%), %.0f cycles each; the others %.0f\n", q[4],
                     100.0 * q[4] / p[3], (double)q[5] / q[4], (double)(p[1] - q[5]) / (double)(p[3] - q[4]));
+        if (p[3] && ctx->stat_blocks > 2) {
+            // how full the phases after the traversal run: a wave executes a phase when any of its lanes needs it
+            const unsigned long long* n = slots.data() + 2 * RTAMD_STAT_STRIDE + ST_COUNT;
+            const char* names[4] = {"hit", "setup", "lighting", "return"};
+            fprintf(stderr, "[rtamd profile]   phases after the traversal:");
+            for (int k = 0; k < 4; k++)
+                fprintf(stderr, " %s in %.1f %% of the iterations for %.1f lanes each;", names[k], 100.0 * n[2 * k] / p[3], n[2 * k] ? (double)n[2 * k + 1] / n[2 * k] : 0.0);
+            fprintf(stderr, "\n");
+        }
         if (p[3] && ctx->stat_blocks > 1)
             fprintf(stderr, "[rtamd profile]   most iterations in one wave %llu, longest-running wave %llu cycles\n", q[6], q[7]);
     }
