@@ -976,7 +976,16 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         const uint32_t want = (uint32_t)RTAMD_CUBE | (DLEAF_DIAG << 8), mask = 0xffu | (DLEAF_DIAG << 8);
         DVisit& D = dv_dfs[i];
         if ((D.vflags_class & RTAMD_VISIT_CSG) || (D.kind_flags & mask) != want) continue;
-        const bool joins = i + 1 < dv_dfs.size() && dv_dfs[i + 1].run > 0 &&
+        const bool joins = i + 1 < dv_dfs.size() && dv_dfs[i + 1].run > 0 && (dv_dfs[i + 1].kind_flags & mask) == want &&
+                           ((dv_dfs[i + 1].kind_flags ^ D.kind_flags) & (RTAMD_LEAF_SHADOW << 8)) == 0;
+        D.run = joins ? dv_dfs[i + 1].run + 1 : 1;
+    }
+    // runs of planes with the same shadow flag (the walls of a room): the kernels for scenes with CSG have a loop of their own for them
+    for (size_t i = dv_dfs.size(); i-- > 0;) {
+        DVisit& D = dv_dfs[i];
+        if ((D.vflags_class & RTAMD_VISIT_CSG) || (D.kind_flags & 0xffu) != (uint32_t)RTAMD_PLANE) continue;
+        const bool joins = i + 1 < dv_dfs.size() && dv_dfs[i + 1].run > 0 && (dv_dfs[i + 1].kind_flags & 0xffu) == (uint32_t)RTAMD_PLANE &&
+                           !(dv_dfs[i + 1].vflags_class & RTAMD_VISIT_CSG) &&
                            ((dv_dfs[i + 1].kind_flags ^ D.kind_flags) & (RTAMD_LEAF_SHADOW << 8)) == 0;
         D.run = joins ? dv_dfs[i + 1].run + 1 : 1;
     }
