@@ -18,6 +18,9 @@
         kernel time of each rank's part of a frame (what one GPU of 1, 2, 4, 8 renders), one part after the other on one GPU
     scripts/gpu_dev.py multi  scene W H
         rtamd_multi_render with the device list naming GPU 0 one to four times: what the split itself costs
+    scripts/gpu_dev.py worst  [--stride N] scene W H ...
+        the frame at its full size against the oracle on every N-th pixel (default: about 14 000 pixels), both modes:
+        the distribution of the differences and the pixels with the largest ones
     scripts/gpu_dev.py phase  scene W H
         three frames per mode; with the -DRTAMD_PROFILE build (RTAMD_LIB_DIR=ray-tracer_amd/lib_prof RTAMD_PROFILE_DUMP=1)
         the library prints cycles per phase of the main loop for each
@@ -209,6 +212,25 @@ def cmd_multi(a):
     return 0
 
 
+def cmd_worst(a):
+    import oracle_lib
+    ctx = rt.Context(0)
+    for name, W, H in triples(a.scenes):
+        stride = a.stride or max(1, W * H // 14000)
+        pix = np.arange(stride // 2, W * H, stride, dtype=np.int64)
+        ref, ref8, _ = oracle_lib.OracleScene(sg_path(name)).render_pixels(pix, W, H, threads=16)
+        ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(W, H).flatten())
+        for mname, mode in MODES.items():
+            rgb, u8 = ctx.render(W, H, mode, want_u8=True)
+            d = np.abs(rgb.reshape(-1, 3)[pix] - ref).max(axis=1)
+            d8 = np.abs(u8.reshape(-1, 3)[pix].astype(int) - ref8.astype(int)).max(axis=1)
+            top = np.argsort(d)[::-1][:6]
+            counts = " ".join(f">{t:g}: {int((d > t).sum())}" for t in (1e-14, 1e-12, 1e-10, 1e-9, 1e-8))
+            print(f"{name} {W}x{H} {mname}: {pix.size} pixels, max {d.max():.3e}, {counts}, 8-bit off {int((d8 > 0).sum())}; worst "
+                  + " ".join(f"({int(pix[i] % W)},{int(pix[i] // W)}: {d[i]:.2e})" for i in top), flush=True)
+    return 0
+
+
 def cmd_phase(a):
     import torch
     ctx = rt.Context(0)
@@ -238,9 +260,11 @@ def main():
     p.add_argument("scenes", nargs="*")
     p = sub.add_parser("host")
     p.add_argument("scenes", nargs="*")
-    for c in ("work", "parts", "multi", "phase"):
+    for c in ("work", "parts", "multi", "phase", "worst"):
         p = sub.add_parser(c)
         p.add_argument("scenes", nargs="*")
+        if c == "worst":
+            p.add_argument("--stride", type=int, default=0)
     a = ap.parse_args()
     if a.cmd == "time":
         return cmd_time_hash(a, False)
@@ -250,8 +274,8 @@ def main():
         return cmd_time_hash(a, True, SUITE)
     if a.cmd == "check":
         return cmd_check(a)
-    if a.cmd in ("work", "parts", "multi", "phase"):
-        return {"work": cmd_work, "parts": cmd_parts, "multi": cmd_multi, "phase": cmd_phase}[a.cmd](a)
+    if a.cmd in ("work", "parts", "multi", "phase", "worst"):
+        return {"work": cmd_work, "parts": cmd_parts, "multi": cmd_multi, "phase": cmd_phase, "worst": cmd_worst}[a.cmd](a)
     return cmd_host(a)
 
 
