@@ -48,6 +48,7 @@ enum { RTAMD_CSG_UNION = 0, RTAMD_CSG_INTERSECTION = 1, RTAMD_CSG_DIFFERENCE = 2
 
 #define RTAMD_MAX_LIGHTS 16
 #define RTAMD_MAX_CHAIN 8           /* transform levels (ancestors + own) of one leaf */
+#define RTAMD_MAX_RAY_LEVELS 80     /* ray_len of one leaf: groups, the CSG objects of one nest (at most 63), its own */
 #define RTAMD_MAX_CSG_LEAVES 64     /* leaves below one top-most CSG node */
 #define RTAMD_CSG_LIST_CAP 24       /* per-lane intersection list of one top-most CSG node */
 #define RTAMD_MAX_MESH_TRIS 4096    /* triangles in one MESH leaf; the flattening host splits longer runs */
@@ -55,7 +56,7 @@ enum { RTAMD_CSG_UNION = 0, RTAMD_CSG_INTERSECTION = 1, RTAMD_CSG_DIFFERENCE = 2
 
 /* One primitive leaf, in depth-first order of the object tree (= the order in which the
  * reference's stable sorts keep intersections of equal t, src/scene.rs:19-26,
- * src/shapes/group.rs:37-45). 144 bytes. */
+ * src/shapes/group.rs:37-45). 152 bytes. */
 typedef struct rtamd_leaf {
     double w2o[12];      /* rows 0..2 of inverse(own) * inverse(parent_n) * ... * inverse(parent_1):
                             world ray -> object ray (src/shape.rs:39-42 applied through every group
@@ -73,6 +74,13 @@ typedef struct rtamd_leaf {
     int32_t chain_len;
     int32_t tri_start;   /* MESH: first triangle in tri_geom / tri_normals */
     int32_t tri_count;   /* MESH: number of triangles; 0 otherwise */
+    int32_t ray_start;   /* first of ray_len 3x4 matrices in `chain`: what the reference multiplies a ray by on its way
+                            to this leaf, one level after the other -- the inverse of every group and CSG object above
+                            it, root first, then its own (src/shape.rs:39-42 called from src/shapes/group.rs:37-45 and
+                            src/shapes/csg.rs:90-97).  For a leaf with groups alone above it that is its chain_start /
+                            chain_len.  RTAMD_MODE_STRICT transforms rays level by level like the reference (w2o, the
+                            product of the levels, differs from that in the last bits); RTAMD_MODE_FAST uses w2o. */
+    int32_t ray_len;     /* at most RTAMD_MAX_RAY_LEVELS; 0 or 1: rays are transformed by w2o in both modes */
 } rtamd_leaf;
 
 /* 232 bytes. */

@@ -13,13 +13,14 @@ CSG_UNION, CSG_INTERSECTION, CSG_DIFFERENCE = range(3)
 LEAF_CLOSED, LEAF_SHADOW, LEAF_SMOOTH = 1, 2, 4
 VISIT_CSG, VISIT_FIRST, VISIT_CLASS_END = 1, 2, 4
 MAX_LIGHTS, MAX_CHAIN, MAX_CSG_LEAVES, CSG_LIST_CAP, MAX_MESH_TRIS, MAX_REMAINING = 16, 8, 64, 24, 4096, 8
+MAX_RAY_LEVELS = 80
 OK, E_INVALID, E_HIP, E_NO_SCENE, E_LIMIT, E_OVERFLOW = 0, -1, -2, -3, -4, -5
 
 
 class Leaf(C.Structure):
     _fields_ = [("w2o", C.c_double * 12), ("p0", C.c_double), ("p1", C.c_double), ("kind", C.c_int32),
                 ("flags", C.c_uint32), ("material", C.c_int32), ("eq_class", C.c_int32), ("chain_start", C.c_int32),
-                ("chain_len", C.c_int32), ("tri_start", C.c_int32), ("tri_count", C.c_int32)]
+                ("chain_len", C.c_int32), ("tri_start", C.c_int32), ("tri_count", C.c_int32), ("ray_start", C.c_int32), ("ray_len", C.c_int32)]
 
 
 class Material(C.Structure):
@@ -61,7 +62,7 @@ class SceneStruct(C.Structure):
 
 
 # sizes the header states
-assert C.sizeof(Leaf) == 144 and C.sizeof(Material) == 232
+assert C.sizeof(Leaf) == 152 and C.sizeof(Material) == 232
 
 
 def doubles(ptr, n):

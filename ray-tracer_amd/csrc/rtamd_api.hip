@@ -19,8 +19,8 @@
 
 #include "rtamd_device.h"
 
-static_assert(sizeof(rtamd_leaf) == 144, "rtamd_leaf layout");
-static_assert(sizeof(DLeaf) == 176, "DLeaf layout");
+static_assert(sizeof(rtamd_leaf) == 152, "rtamd_leaf layout");
+static_assert(sizeof(DLeaf) == 184, "DLeaf layout");
 static_assert(sizeof(rtamd_material) == 232, "rtamd_material layout");
 static_assert(sizeof(rtamd_visit) == 16, "rtamd_visit layout");
 static_assert(sizeof(DVisit) == 128, "DVisit layout");
@@ -277,6 +277,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         (s->n_csg_nodes && !s->csg_nodes) || (s->n_csg_roots && !s->csg_roots) || (s->n_visits && !s->visits))
         return fail(ctx, RTAMD_E_INVALID, "NULL array with a non-zero count");
     std::vector<DLeaf> dl((size_t)s->n_leaves);
+    std::vector<double> ray_levels;  // the levels of the leaves that get DLEAF_LEVELS
     long long order = 0;
     for (int i = 0; i < s->n_leaves; i++) {
         const rtamd_leaf& L = s->leaves[i];
@@ -284,6 +285,8 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         if (L.material < 0 || L.material >= s->n_materials) return fail(ctx, RTAMD_E_INVALID, "leaf material index out of range");
         if (L.chain_len < 1 || L.chain_len > RTAMD_MAX_CHAIN || L.chain_start < 0 || L.chain_start + L.chain_len > s->n_chain)
             return fail(ctx, RTAMD_E_INVALID, "leaf transform chain out of range");
+        if (L.ray_len < 0 || L.ray_len > RTAMD_MAX_RAY_LEVELS || (L.ray_len > 0 && (L.ray_start < 0 || L.ray_start + L.ray_len > s->n_chain)))
+            return fail(ctx, RTAMD_E_INVALID, "leaf ray levels out of range");
         if (L.eq_class < 0 || L.eq_class >= std::max(s->n_classes, 1)) return fail(ctx, RTAMD_E_INVALID, "leaf class out of range");
         int slots = 0;
         if (L.kind == RTAMD_MESH) {
@@ -300,6 +303,24 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         D.p0 = L.p0, D.p1 = L.p1, D.kind = L.kind, D.flags = L.flags, D.material = L.material, D.eq_class = L.eq_class;
         D.chain_start = L.chain_start, D.chain_len = L.chain_len, D.tri_start = L.tri_start, D.tri_count = L.tri_count;
         D.order_base = (int)order;
+        if (L.ray_len > 1) {
+            // A level whose matrix is the identity (a CSG object or a group nobody moved) hands the ray on as it came:
+            // 1 * x + 0 * y + 0 * z (+ 0) is x, at most with another sign on a zero, and the intersection tests never read
+            // the sign of a zero (every division by a component of the ray is behind |component| >= EPSILON).  Such levels
+            // are left out; a leaf with one level left is transformed by w2o, which then is that level (same argument).
+            const size_t first = ray_levels.size();
+            for (int k = 0; k < L.ray_len; k++) {
+                const double* lv = s->chain + ((size_t)L.ray_start + (size_t)k) * 12;
+                bool identity = true;
+                for (int q = 0; q < 12; q++) identity = identity && lv[q] == (q % 5 == 0 ? 1.0 : 0.0);
+                if (!identity) ray_levels.insert(ray_levels.end(), lv, lv + 12);
+            }
+            const size_t n = (ray_levels.size() - first) / 12;
+            if (n > 1)
+                D.flags |= DLEAF_LEVELS, D.ray_start = (int32_t)(first / 12), D.ray_len = (int32_t)n;
+            else
+                ray_levels.resize(first);
+        }
         const double* m = L.w2o;
         if (m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0 && m[0] != 0.0 && m[5] != 0.0 &&
             m[10] != 0.0) {
@@ -474,7 +495,9 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
             const rtamd_leaf &A = s->leaves[a], &B = s->leaves[b];
             return B.kind == RTAMD_MESH && !in_csg[(size_t)b] && has_box[(size_t)b] && std::memcmp(A.w2o, B.w2o, sizeof A.w2o) == 0 &&
                    A.flags == B.flags && A.material == B.material && A.eq_class == B.eq_class && A.chain_len == B.chain_len &&
-                   std::memcmp(s->chain + (size_t)A.chain_start * 12, s->chain + (size_t)B.chain_start * 12, (size_t)A.chain_len * 12 * sizeof(double)) == 0;
+                   std::memcmp(s->chain + (size_t)A.chain_start * 12, s->chain + (size_t)B.chain_start * 12, (size_t)A.chain_len * 12 * sizeof(double)) == 0 &&
+                   std::max(A.ray_len, 1) == std::max(B.ray_len, 1) &&
+                   (A.ray_len <= 1 || std::memcmp(s->chain + (size_t)A.ray_start * 12, s->chain + (size_t)B.ray_start * 12, (size_t)A.ray_len * 12 * sizeof(double)) == 0);
         };
         for (int i = 0; i < s->n_leaves;) {
             const rtamd_leaf& L = s->leaves[i];
@@ -620,6 +643,7 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
         return true;
     };
     if ((rc = upload(ctx, s->chain, (size_t)s->n_chain * 12, &d.chain))) return rc;
+    if ((rc = upload(ctx, ray_levels.data(), ray_levels.size(), &d.ray_levels))) return rc;
     if ((rc = upload(ctx, s->tri_geom, (size_t)s->n_tris * 9, &d.tri_geom))) return rc;
     if ((rc = upload(ctx, s->tri_normals, (size_t)s->n_tris * 9, &d.tri_normals))) return rc;
     if ((rc = upload(ctx, s->materials, (size_t)s->n_materials, &d.materials))) return rc;
@@ -983,8 +1007,10 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     // runs of planes with the same shadow flag (the walls of a room): the kernels for scenes with CSG have a loop of their own for them
     for (size_t i = dv_dfs.size(); i-- > 0;) {
         DVisit& D = dv_dfs[i];
-        if ((D.vflags_class & RTAMD_VISIT_CSG) || (D.kind_flags & 0xffu) != (uint32_t)RTAMD_PLANE) continue;
-        const bool joins = i + 1 < dv_dfs.size() && dv_dfs[i + 1].run > 0 && (dv_dfs[i + 1].kind_flags & 0xffu) == (uint32_t)RTAMD_PLANE &&
+        // (not the planes below groups: the loop reads the record's matrix alone, and strict arithmetic takes their rays level by level)
+        const uint32_t mask = 0xffu | (DLEAF_LEVELS << 8);
+        if ((D.vflags_class & RTAMD_VISIT_CSG) || (D.kind_flags & mask) != (uint32_t)RTAMD_PLANE) continue;
+        const bool joins = i + 1 < dv_dfs.size() && dv_dfs[i + 1].run > 0 && (dv_dfs[i + 1].kind_flags & mask) == (uint32_t)RTAMD_PLANE &&
                            !(dv_dfs[i + 1].vflags_class & RTAMD_VISIT_CSG) &&
                            ((dv_dfs[i + 1].kind_flags ^ D.kind_flags) & (RTAMD_LEAF_SHADOW << 8)) == 0;
         D.run = joins ? dv_dfs[i + 1].run + 1 : 1;

@@ -5,7 +5,7 @@
 
 #include "../../include/rtamd.h"
 
-// Device copy of an rtamd_leaf plus what the upload derives from the scene. 176 bytes.
+// Device copy of an rtamd_leaf plus what the upload derives from the scene. 184 bytes.
 struct DLeaf {
     double w2o[12];
     double p0, p1;
@@ -18,10 +18,14 @@ struct DLeaf {
     int32_t tri_start;
     int32_t tri_count;
     int32_t order_base;  // rank of this leaf's first possible intersection in depth-first order
-    int32_t pad_;
+    int32_t ray_start;   // DLEAF_LEVELS: first of ray_len matrices of DScene::ray_levels a ray passes on its way to the leaf
     double inv_diag[3];  // DLEAF_DIAG: 1 / w2o[0], 1 / w2o[5], 1 / w2o[10]
+    int32_t ray_len;
+    int32_t pad_;
 };
-#define DLEAF_DIAG 0x100u  // device-side flag: the 3x3 part of w2o is diagonal
+#define DLEAF_DIAG 0x100u    // device-side flag: the 3x3 part of w2o is diagonal
+#define DLEAF_LEVELS 0x200u  // device-side flag: w2o is the product of two or more levels (groups, CSG objects, the leaf's own);
+                             // STRICT arithmetic transforms rays by the levels one after the other (src/shape.rs:39-42)
 
 // Everything shading a hit on one leaf needs, in one record, so that a lane finds it with one level of
 // loads: the leaf's parameters, the first two levels of its transform chain (deeper chains continue in
@@ -90,6 +94,7 @@ struct DScene {
     const DLeaf* leaves;
     const DShade* shade;  // one per leaf
     const double* chain;
+    const double* ray_levels;  // leaves with DLEAF_LEVELS: their levels, outermost first (12 doubles each)
     const double* tri_geom;
     const double* tri_sorted;  // the same triangles in the order of the runs the traversal tests (9 doubles each)
     const int32_t* tri_key;    // per triangle of tri_sorted: leaf << RTAMD_KEY_SHIFT | slot of its place in tri_geom

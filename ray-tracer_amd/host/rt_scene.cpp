@@ -260,6 +260,7 @@ struct Flattener {
     std::vector<Material> mats;            // host copies for de-duplication
     std::vector<const Shape*> leaf_shape;  // representative shape per leaf
     std::vector<int> leaf_root;            // csg root index or -1
+    std::vector<Matrix4x4> ray_levels;     // inverse of every group and CSG object above the shape being visited, root first
     // open mesh run
     const Shape* run_parent = nullptr;
     bool run_open = false;
@@ -345,6 +346,27 @@ struct Flattener {
         L.flags = s.shadow() ? RTAMD_LEAF_SHADOW : 0;
         L.chain_start = push_chain(s);
         L.chain_len = (int)s.parent_transforms().size() + 1;
+        // The levels a ray passes on its way to the leaf (src/shape.rs:39-42 at every group and CSG object above it).  Groups
+        // alone above the leaf: the levels of the chain just written.  Below a CSG object the leaf's parent_transforms stop at
+        // (or never saw) that object, so the levels get a run of `chain` of their own.
+        bool same_levels = root < 0 && ray_levels.size() + 1 == (size_t)L.chain_len;
+        for (size_t i = 0; same_levels && i < ray_levels.size(); i++) {
+            double lv[12];
+            put34(lv, ray_levels[i]);
+            same_levels = std::memcmp(lv, &fs.chain[((size_t)L.chain_start + i) * 12], sizeof lv) == 0;
+        }
+        if (same_levels) {
+            L.ray_start = L.chain_start, L.ray_len = L.chain_len;
+        } else {
+            if (ray_levels.size() + 1 > RTAMD_MAX_RAY_LEVELS) throw Error("groups and CSG objects nested deeper than the device limit (RTAMD_MAX_RAY_LEVELS)");
+            L.ray_start = (int)(fs.chain.size() / 12), L.ray_len = (int)ray_levels.size() + 1;
+            for (auto& lv : ray_levels) {
+                fs.chain.resize(fs.chain.size() + 12);
+                put34(&fs.chain[fs.chain.size() - 12], lv);
+            }
+            fs.chain.resize(fs.chain.size() + 12);
+            put34(&fs.chain[fs.chain.size() - 12], inv_or_throw(s.props.transform, "a shape"));
+        }
         run_open = false;
         switch (s.kind()) {
             case Kind::Sphere: L.kind = RTAMD_SPHERE; break;
@@ -384,14 +406,19 @@ struct Flattener {
     void visit(const Shape& s, const Matrix4x4& accum, const Shape* parent, int root) {
         if (s.kind() == Kind::Group) {
             auto& g = static_cast<const Group&>(s);
-            Matrix4x4 a = inv_or_throw(g.transform(), "a group") * accum;
+            Matrix4x4 own = inv_or_throw(g.transform(), "a group");
+            Matrix4x4 a = own * accum;
             run_open = false;
+            ray_levels.push_back(own);
             for (auto& ch : g.children) visit(*ch, a, &s, root);
+            ray_levels.pop_back();
             run_open = false;
         } else if (s.kind() == Kind::Csg) {
             auto& c = static_cast<const Csg&>(s);
-            Matrix4x4 a = inv_or_throw(c.transform(), "a csg") * accum;
+            Matrix4x4 own = inv_or_throw(c.transform(), "a csg");
+            Matrix4x4 a = own * accum;
             run_open = false;
+            ray_levels.push_back(own);
             bool top = root < 0;
             int my_root = root;
             if (top) {
@@ -410,6 +437,7 @@ struct Flattener {
             visit(*c.right, a, &s, my_root);
             run_open = false;
             n.leaf_hi = (int)fs.leaves.size();
+            ray_levels.pop_back();
             fs.csg_nodes.push_back(n);
             if (top) {
                 rtamd_csg_root& r = fs.csg_roots[my_root];

@@ -41,6 +41,8 @@ pub struct rtamd_leaf {
     pub chain_len: i32,
     pub tri_start: i32,
     pub tri_count: i32,
+    pub ray_start: i32,
+    pub ray_len: i32,
 }
 #[repr(C)]
 pub struct rtamd_material {

@@ -82,6 +82,31 @@ def test_group_material_is_inherited_as_refresh_parents_does(rt):
     assert s.leaves[0].chain_len == 2 and s.leaves[0].w2o[3] == -1.0 and s.leaves[0].w2o[7] == -2.0
 
 
+def test_ray_levels_follow_the_objects_a_ray_passes_not_the_parents_a_normal_sees(rt):
+    """A ray is transformed at every group and CSG object above a leaf (src/shape.rs:39-42 from src/shapes/group.rs:37-45 and
+    src/shapes/csg.rs:90-97); normals and patterns go through parent_transforms, which Group::refresh_parents (group.rs:76-89)
+    does not carry past a CSG object.  The flat scene keeps both lists."""
+    b = rt.WorldBuilder()
+    b.camera(8, 8, 1.0)
+    b.group_begin(sgtext.translation(1, 0, 0))
+    b.csg_begin("difference", sgtext.scaling(2, 2, 2))
+    b.add("sphere", sgtext.translation(0, 3, 0))
+    b.group_begin(sgtext.translation(0, 0, 5))
+    b.add("cube")
+    b.group_end()
+    b.csg_end()
+    b.add("cone", sgtext.scaling(1, 4, 1))
+    b.group_end()
+    s = b.scene().flatten().scene
+    sphere, cube, cone = s.leaves[0], s.leaves[1], s.leaves[2]
+    lv = lambda L, k: np.array(s.chain[(L.ray_start + k) * 12:(L.ray_start + k + 1) * 12]).reshape(3, 4)
+    assert (sphere.chain_len, sphere.ray_len) == (1, 3) and (cube.chain_len, cube.ray_len) == (1, 4) and (cone.chain_len, cone.ray_len) == (2, 2)
+    assert (cone.ray_start, cone.ray_len) == (cone.chain_start, cone.chain_len)
+    assert lv(sphere, 0)[0, 3] == -1.0 and lv(sphere, 1)[0, 0] == 0.5 and lv(sphere, 2)[1, 3] == -3.0
+    assert lv(cube, 0)[0, 3] == -1.0 and lv(cube, 1)[1, 1] == 0.5 and lv(cube, 2)[2, 3] == -5.0 and np.array_equal(lv(cube, 3), np.eye(4)[:3])
+    assert lv(cone, 0)[0, 3] == -1.0 and lv(cone, 1)[1, 1] == 0.25
+
+
 def test_every_declaration_of_the_host_header_is_exported_and_compiles_as_c99(rt, tmp_path):
     hdr = open(os.path.join(ROOT, "include", "rtamd_host.h")).read()
     declared = set(re.findall(r"\b(rth_\w+)\s*\(", hdr))

@@ -22,7 +22,7 @@ def _frame(rt, ctx, w, h, mode):
 
 
 CASES = [("cover", 3840, 2160, 3001), ("cylinders", 3840, 2160, 3001), ("tables", 3840, 2160, 3001),
-         ("reflect_refract", 3840, 2160, 3001), ("glass_spheres", 7680, 4320, 9001), ("groups", 7680, 4320, 30011),
+         ("reflect_refract", 3840, 2160, 3001), ("glass_spheres", 7680, 4320, 9001), ("groups", 7680, 4320, 2395),
          ("csg", 7680, 4320, 9001), ("teapot_room", 3840, 2160, 27001)]
 
 
@@ -65,7 +65,11 @@ def test_full_size_frame(rt, oracle, gpu_ctx, name, w, h, stride):
     assert off <= 1e-5 * w * h
     got = strict.reshape(-1, 3)[idx].cpu().numpy()
     worst = float(np.abs(got - ref).max())
+    # (the lattice of groups is the one on which, while strict arithmetic still multiplied rays by the product of their
+    # levels, one grazing pixel in 13 853 came out 7.5e-9 off; taken level by level as the reference does: 1.1e-16)
     assert worst <= 1e-10
+    if name == "groups":
+        assert worst <= 1e-14
 
 
 def test_teapot_room_quarter_frame(rt, oracle, gpu_ctx):

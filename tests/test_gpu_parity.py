@@ -2,10 +2,10 @@
 oracle's committed frames, the reference author's renders, and known answers of the reference's tests.
 
 Tolerances.  The result is IEEE f64 colour.  STRICT mode evaluates the reference's operations in its
-order without fused multiply-add: it differs from the oracle only where libm's pow and the device's
-differ by an ulp, or where a transform chain is composed on the host instead of applied level by level
-(groups): |diff| <= 1e-10 per channel.  FAST mode allows FMA contraction and reciprocal multiplies:
-|diff| <= 1e-8.  Both must meet the bar of the 8-bit output: every channel within 1 LSB of the oracle's on
+order without fused multiply-add -- rays go through groups and CSG objects level by level as the reference
+takes them -- and differs from the oracle only where libm's pow and the device's differ by an ulp:
+|diff| <= 1e-10 per channel (measured: 2.3e-16).  FAST mode allows FMA contraction and reciprocal multiplies and
+transforms a ray by the product of its levels: |diff| <= 1e-8.  Both must meet the bar of the 8-bit output: every channel within 1 LSB of the oracle's on
 >= 99.9 % of pixels (in practice they are equal)."""
 import importlib
 import os
@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 from PIL import Image
 
+import sgtext as sg
 from conftest import ALL_SCENES, GOLDEN, golden_frame, sg_path
 
 pytestmark = pytest.mark.gpu
@@ -230,6 +231,68 @@ def test_nested_csg_with_long_intersection_lists(rt, oracle, gpu_ctx, tmp_path):
         assert gpu_ctx.stats().csg_overflows == 0
         assert np.abs(rgb - ref).max() <= tol, mode
         assert (np.abs(u8.astype(int) - ref8.astype(int)).max(axis=2) <= 1).mean() >= 0.999
+
+
+def _levels_scene(path, w, h):
+    """Groups three deep, a transformed CSG object holding a transformed group, smooth triangles below two groups."""
+    s = sg.SG()
+    shear = np.eye(4)
+    shear[0, 1], shear[2, 0] = 0.3, -0.2
+    floor = s.mat(color=(0.8, 0.8, 0.7), specular=0.1, reflective=0.2, pattern=("checkers", (0.2, 0.2, 0.2), (0.9, 0.9, 0.9), sg.translation(0.13, 0.37, 0.21) @ sg.scaling(0.7, 0.7, 0.7)))  # (the floor well inside a layer of the checkers)
+    shiny = s.mat(color=(0.9, 0.3, 0.2), specular=0.9, shininess=300.0, reflective=0.3)
+    glass = s.mat(color=(0.1, 0.1, 0.2), diffuse=0.2, transparency=0.8, reflective=0.6, ri=1.5)
+    ring = s.mat(color=(0.2, 0.6, 0.9), pattern=("ring", (0.2, 0.6, 0.9), (0.9, 0.8, 0.1), sg.scaling(0.3, 0.3, 0.3) @ sg.rotation_x(0.4)))
+    s.shape("plane", floor, sg.translation(0, -1.7, 0))
+    # groups three deep
+    s.group(2, shiny, sg.translation(-2.1, 0.3, 0.4) @ sg.rotation_y(0.7) @ sg.scaling(1.2, 0.8, 1.1))
+    s.group(2, shiny, sg.rotation_z(0.5) @ shear)
+    s.group(2, ring, sg.translation(0.3, 0.9, -0.2) @ sg.rotation_x(1.1))
+    s.shape("cone", ring, sg.scaling(0.6, 1.3, 0.6), mn=-1.0, mx=0.0, closed=True)
+    s.shape("cylinder", shiny, sg.translation(0.2, 0.1, 0.3) @ sg.scaling(0.35, 1.0, 0.35), mn=-0.4, mx=0.9, closed=True)
+    s.shape("sphere", glass, sg.translation(0.1, -0.6, 0.2) @ sg.scaling(0.7, 0.5, 0.7))
+    s.shape("cube", ring, sg.translation(0.9, -0.9, 0.8) @ sg.rotation_y(0.3) @ sg.scaling(0.4, 0.4, 0.4))
+    # A transformed CSG object with a transformed group inside.  Its leaves have normals that vary smoothly (spheres, an
+    # open cylinder): Group::refresh_parents (src/shapes/group.rs:76-89) does not reach below a CSG object, so normal_at
+    # (src/shape.rs:44-70) leaves the object's transform out, and where a cube or an end cap then takes the normal of another
+    # face, over_point slides along the surface and the shadow test meets that surface at t = 0 +- rounding: the reference's
+    # own picture of such a face changes pixel by pixel when the camera moves by 1e-9.
+    s.csg("difference", shiny, sg.translation(1.9, 0.1, 0.6) @ sg.rotation_y(-0.4) @ sg.scaling(1.1, 1.3, 0.9))
+    s.shape("sphere", shiny, sg.rotation_y(0.2) @ sg.scaling(1.0, 0.8, 1.0))
+    s.group(2, glass, sg.translation(0.2, 0.3, -0.5) @ sg.rotation_z(0.6))
+    s.shape("sphere", glass, sg.scaling(0.9, 0.9, 0.9))
+    s.shape("cylinder", ring, sg.rotation_x(1.3) @ sg.scaling(0.4, 1.0, 0.4), mn=-2.0, mx=2.0, closed=False)
+    # smooth triangles below two groups
+    v, f = sg.icosahedron()
+    s.group(1, shiny, sg.translation(-0.1, 1.9, 1.5) @ sg.rotation_x(0.3))
+    s.group(len(f), shiny, sg.rotation_y(0.9) @ sg.scaling(0.8, 0.6, 0.8))
+    for a, b, c in f:
+        s.tri(shiny, v[a], v[b], v[c], normals=(v[a], v[b], v[c]))
+    s.light((-4.0, 7.0, -6.0), (0.9, 0.9, 0.9))
+    s.light((5.0, 3.0, -4.0), (0.3, 0.3, 0.4))
+    s.set_camera(w, h, 1.0, (0.3, 1.6, -7.5), (0.0, 0.2, 0.0))
+    return s.write(path)
+
+
+def test_strict_takes_rays_through_groups_and_csg_objects_level_by_level(rt, oracle, gpu_ctx, tmp_path):
+    """The reference transforms a ray once per group and CSG object above a leaf (src/shape.rs:39-42 from
+    src/shapes/group.rs:37-45 and src/shapes/csg.rs:90-97), rounding at every level; one multiplication by the product of
+    those matrices rounds elsewhere, and on a grazing ray the last bits of t decide what the pixel shows.  Strict arithmetic
+    goes level by level: groups three deep with rotations, unequal scales and a shear, a transformed CSG object holding a
+    transformed group, and smooth triangles below two groups come out as the oracle renders them -- to 1e-14 (what remains
+    is the last bit of pow in the highlight), most pixels to the bit.  Fast arithmetic uses the product: its own bar."""
+    w, h = 200, 120
+    p = _levels_scene(tmp_path / "levels.sg", w, h)
+    flat = rt.Scene.from_sg(p).flatten()
+    assert max(flat.scene.leaves[i].ray_len for i in range(flat.scene.n_leaves)) == 4
+    ref, ref8, _ = oracle.OracleScene(p).render(w, h, threads=8)
+    gpu_ctx.upload(flat)
+    rgb, u8 = gpu_ctx.render(w, h, rt.MODE_STRICT, want_u8=True)
+    assert len(np.unique(u8.reshape(-1, 3), axis=0)) > 500  # a picture of the objects, not of the floor alone
+    assert np.abs(rgb - ref).max() <= 1e-14 and np.array_equal(u8, ref8)
+    assert (rgb == ref).all(axis=2).mean() >= 0.99
+    fast = gpu_ctx.render(w, h, rt.MODE_FAST)
+    off = np.abs(fast - ref).max(axis=2) > FAST_TOL  # (a ray that grazes a pattern boundary or an edge may land on its other side)
+    assert off.sum() <= 3, np.argwhere(off)
 
 
 def test_containers_with_duplicate_objects_under_bounds_records(rt, oracle, gpu_ctx, tmp_path):

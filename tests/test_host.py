@@ -220,6 +220,20 @@ def test_flatten_invariants(rt, name):
     first_of_class = {}
     for i, L in enumerate(leaves):
         assert 0 <= L.material < s.n_materials and 1 <= L.chain_len <= abi.MAX_CHAIN
+        # the levels a ray passes on its way to the leaf: their product is w2o (to rounding), the last one the leaf's own inverse
+        # (= the last of its chain); groups alone above the leaf: the chain itself; below a CSG object the chain is the leaf's own
+        assert 1 <= L.ray_len <= abi.MAX_RAY_LEVELS and 0 <= L.ray_start and L.ray_start + L.ray_len <= s.n_chain
+        lv = [np.vstack([np.array(s.chain[(L.ray_start + k) * 12:(L.ray_start + k + 1) * 12]).reshape(3, 4), [0, 0, 0, 1]]) for k in range(L.ray_len)]
+        prod = np.eye(4)
+        for m in lv:
+            prod = m @ prod
+        assert np.allclose(prod[:3], np.array(L.w2o).reshape(3, 4), rtol=1e-12, atol=1e-12)
+        own = np.array(s.chain[(L.chain_start + L.chain_len - 1) * 12:(L.chain_start + L.chain_len) * 12])
+        assert np.array_equal(lv[-1][:3].ravel(), own)
+        if i in in_csg:
+            assert L.chain_len == 1
+        else:
+            assert (L.ray_start, L.ray_len) == (L.chain_start, L.chain_len)
         # classes are dense and numbered by first appearance; equal leaves share kind and material values
         assert 0 <= L.eq_class <= len(first_of_class) and L.eq_class < s.n_classes
         rep = leaves[first_of_class.setdefault(L.eq_class, i)]
