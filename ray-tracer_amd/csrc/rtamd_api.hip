@@ -684,16 +684,64 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     std::vector<DVisit> dv;
     std::vector<int32_t> class_mat((size_t)std::max(s->n_classes, 1), 0);
     double diag_thr = 0.0;
-    // the record of a CSG object: the bounds of all its leaves (no bounds at all when one of them has none, or is a
-    // cone: see the bounds records below)
-    auto csg_record = [&](DVisit& D, int root) {
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        bool all = true;
-        for (int l = s->csg_roots[root].leaf_lo; l < s->csg_roots[root].leaf_hi; l++) {
-            all = all && has_box[(size_t)l] && s->leaves[l].kind != RTAMD_CONE;
-            for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], boxes[(size_t)l * 6 + k]), hi[k] = std::max(hi[k], boxes[(size_t)l * 6 + 3 + k]);
+    // The record of a CSG object: bounds of everything its operations can keep (no bounds at all when that takes in a leaf
+    // that has none, or a cone: see the bounds records below).  What the filter of src/shapes/csg.rs:54-82 keeps of a
+    // difference are hits on the left child and hits of the right child between an odd and an even hit of the left one; of
+    // an intersection, hits of either child between such hits of the other.  A sphere or a cube gives a ray none or two
+    // hits (src/shapes/sphere.rs:40-55, src/shapes/cube.rs:46-66), with nothing but its inside between them: where the
+    // left child of a difference, or either child of an intersection, is such a leaf, its box holds all that is kept --
+    // whatever the other child is, a plane included.  Everything else (unions, groups, children that are cylinders or
+    // objects themselves) gets the bounds of its leaves together.
+    struct CsgBox {
+        double lo[3], hi[3];
+        bool finite, pair;
+    };
+    std::function<CsgBox(int, int, int, int)> csg_range_box = [&](int root, int a, int b, int below) {
+        const rtamd_csg_root& R = s->csg_roots[root];
+        int node = -1;  // the CSG node that is this range of leaves (children come before their parents: post-order)
+        for (int q = R.node_start; q < below; q++)
+            if (s->csg_nodes[q].leaf_lo == a && s->csg_nodes[q].leaf_hi == b && b > a) node = q;
+        CsgBox B{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}, true, false};
+        auto take_in = [&](const CsgBox& C) {
+            B.finite = B.finite && C.finite;
+            for (int k = 0; k < 3; k++) B.lo[k] = std::min(B.lo[k], C.lo[k]), B.hi[k] = std::max(B.hi[k], C.hi[k]);
+        };
+        if (node < 0) {  // a leaf, or the leaves of a group
+            for (int l = a; l < b; l++) {
+                CsgBox C{};
+                for (int k = 0; k < 3; k++) C.lo[k] = boxes[(size_t)l * 6 + k], C.hi[k] = boxes[(size_t)l * 6 + 3 + k];
+                C.finite = has_box[(size_t)l] && s->leaves[l].kind != RTAMD_CONE;
+                take_in(C);
+            }
+            B.pair = b - a == 1 && B.finite && (s->leaves[a].kind == RTAMD_SPHERE || s->leaves[a].kind == RTAMD_CUBE);
+            return B;
         }
-        for (int k = 0; k < 3; k++) D.w2o[k] = all ? lo[k] : -INFINITY, D.w2o[3 + k] = all ? hi[k] : INFINITY;
+        const rtamd_csg_node& N = s->csg_nodes[node];
+        const CsgBox L = csg_range_box(root, N.leaf_lo, N.leaf_mid, node), Rt = csg_range_box(root, N.leaf_mid, N.leaf_hi, node);
+        // (`left.includes`, src/shapes/csg.rs:64, goes by value: a leaf of the right child that equals one of the left child
+        // counts as a hit of the left child wherever the groups above it put it -- then the leaves' bounds together)
+        const int n_left = N.leaf_mid - N.leaf_lo;
+        const bool by_place = n_left >= 64 || (N.left_mask >> n_left) == 0;
+        if (by_place && N.op == RTAMD_CSG_DIFFERENCE && L.pair) {
+            B = L;
+        } else if (by_place && N.op == RTAMD_CSG_INTERSECTION && (L.pair || Rt.pair)) {
+            B = L.pair ? L : Rt;
+            if (L.pair && Rt.pair) {
+                CsgBox C = B;
+                for (int k = 0; k < 3; k++) C.lo[k] = std::max(L.lo[k], Rt.lo[k]), C.hi[k] = std::min(L.hi[k], Rt.hi[k]);
+                if (C.lo[0] <= C.hi[0] && C.lo[1] <= C.hi[1] && C.lo[2] <= C.hi[2]) B = C;  // (boxes apart: nothing is kept; either box will do)
+            }
+        } else {
+            take_in(L), take_in(Rt);
+        }
+        B.pair = false;
+        return B;
+    };
+    auto csg_record = [&](DVisit& D, int root) {
+        const rtamd_csg_root& R = s->csg_roots[root];
+        const CsgBox B = getenv("RTAMD_CSG_LOOSE_BOX") ? csg_range_box(root, R.leaf_lo, R.leaf_hi, R.node_start)  // (diagnostic: the leaves' bounds together)
+                                                      : csg_range_box(root, R.leaf_lo, R.leaf_hi, R.node_start + R.node_count);
+        for (int k = 0; k < 3; k++) D.w2o[k] = B.finite ? B.lo[k] : -INFINITY, D.w2o[3 + k] = B.finite ? B.hi[k] : INFINITY;
     };
     auto leaf_record = [&](DVisit& D, int leaf, const Run* run) {  // run: of a MESH leaf, which of its runs the record is for
         const DLeaf& L = dl[leaf];
