@@ -39,6 +39,7 @@ struct rtamd_ctx {
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
     int max_blocks[3][128] = {};  // [mode][variant]; [2]: the fast kernels with teams of lanes per pixel
+    bool has_levels = false;      // the scene has leaves with DLEAF_LEVELS: strict arithmetic runs the kernels that know them
     bool count_work = false;       // launches use the kernels that count the tests they execute (rtamd_count_work)
     int stat_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -155,7 +156,9 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
     for (int v = 0; v < 128; v++) {
         int b = 0;
         if ((e = rtamd_occupancy_strict(v, &b)) != hipSuccess) return bail("occupancy(strict)", e);
-        ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, b) * ctx->num_cus;
+        int bl = 0;  // (the strict kernels with and without the code for levels run under one entry: the smaller grid fits both)
+        if ((e = rtamd_occupancy_levels(v, &bl)) != hipSuccess) return bail("occupancy(levels)", e);
+        ctx->max_blocks[RTAMD_MODE_STRICT][v] = std::max(1, std::min(b, bl)) * ctx->num_cus;
         if ((e = rtamd_occupancy_fast(v, &b)) != hipSuccess) return bail("occupancy(fast)", e);
         ctx->max_blocks[RTAMD_MODE_FAST][v] = std::max(1, b) * ctx->num_cus;
         if ((e = rtamd_occupancy_teams(v, &b)) != hipSuccess) return bail("occupancy(teams)", e);
@@ -1115,6 +1118,8 @@ static int scene_upload(rtamd_ctx* ctx, const rtamd_scene* s) {
     ctx->has_csg = s->n_csg_roots > 0;
     bool has_bounds = false;
     ctx->variant = ctx->has_csg ? (csg_small ? 3 : 2) : (s->n_tris > 0 ? 1 : 0);
+    ctx->has_levels = false;
+    for (const DLeaf& L : dl) ctx->has_levels = ctx->has_levels || (L.flags & DLEAF_LEVELS) != 0;
     if (ctx->has_csg && s->n_tris == 0) ctx->variant |= 32;  // the CSG kernels without the code for triangles
     if (!ctx->has_csg)  // the CSG kernels are built without the slab code
         for (int i = 0; i < s->n_leaves; i++) {
@@ -1318,7 +1323,8 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
     // recorded during capture can be neither waited for nor read afterwards (kernel_ms then stays 0).
     const bool time_it = !static_scratch;
     if (time_it && !ctx->skip_ev0) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
-    hipError_t e = mode == RTAMD_MODE_STRICT ? rtamd_launch_strict(ctx->ds, w, variant, blocks, stream)
+    hipError_t e = mode == RTAMD_MODE_STRICT ? (ctx->has_levels ? rtamd_launch_levels(ctx->ds, w, variant, blocks, stream)
+                                                                : rtamd_launch_strict(ctx->ds, w, variant, blocks, stream))
                    : w.team > 1              ? rtamd_launch_teams(ctx->ds, w, variant & 63, blocks, stream)
                                              : rtamd_launch_fast(ctx->ds, w, variant, blocks, stream);
     if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

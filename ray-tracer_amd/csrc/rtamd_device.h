@@ -186,6 +186,9 @@ hipError_t rtamd_launch_strict(const DScene& s, const DWork& w, int variant, int
 hipError_t rtamd_launch_fast(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_occupancy_strict(int variant, int* blocks_per_cu);
 hipError_t rtamd_occupancy_fast(int variant, int* blocks_per_cu);
+// the strict kernels for scenes with leaves that have DLEAF_LEVELS
+hipError_t rtamd_launch_levels(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
+hipError_t rtamd_occupancy_levels(int variant, int* blocks_per_cu);
 // the fast kernels with teams of lanes per pixel (variant: without the counting bit)
 hipError_t rtamd_launch_teams(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_occupancy_teams(int variant, int* blocks_per_cu);

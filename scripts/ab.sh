@@ -4,6 +4,6 @@
 a=$1; b=$2; shift 2
 for r in 1 2 3; do
   for d in "$a" "$b"; do
-    RTAMD_LIB_DIR=$d timeout -k 10 300 python -u scripts/gpu_dev.py time --modes fast --frames 8 "$@" | sed "s|^|$d r$r: |" || exit 1
+    RTAMD_LIB_DIR=$d timeout -k 10 300 python -u scripts/gpu_dev.py time --modes ${AB_MODES:-fast} --frames 8 "$@" | sed "s|^|$d r$r: |" || exit 1
   done
 done
