@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
     for (i = 0; i < 3; i++) {
         leaves[i].flags = RTAMD_LEAF_SHADOW, leaves[i].material = i, leaves[i].eq_class = i;
         leaves[i].chain_start = i, leaves[i].chain_len = 1; /* one level: the leaf's own inverse */
+        leaves[i].ray_start = i, leaves[i].ray_len = 1;     /* ... which is all a ray passes, too (w2o is that matrix) */
         memcpy(chain + 12 * i, leaves[i].w2o, 12 * sizeof(double));
         leaves[i].p0 = -INFINITY, leaves[i].p1 = INFINITY;
         visits[i].unit = i, visits[i].flags = RTAMD_VISIT_FIRST | RTAMD_VISIT_CLASS_END, visits[i].eq_class = i, visits[i].class_material = i;
