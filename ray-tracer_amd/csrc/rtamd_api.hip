@@ -1313,12 +1313,24 @@ static int prepare(rtamd_ctx* ctx, int mode, DWork& w, bool static_scratch, int*
     return RTAMD_OK;
 }
 
+// The counters of the work queue back to zero (RTAMD_QUEUES of them, RTAMD_QUEUE_STRIDE words apart).
+__global__ void rtamd_zero_queue(unsigned long long* head) {
+    for (unsigned i = threadIdx.x; i < RTAMD_QUEUES * RTAMD_QUEUE_STRIDE; i += blockDim.x) head[i] = 0;
+}
+
 static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool static_scratch = false) {
     int blocks = 0;
     const int prc = prepare(ctx, mode, w, static_scratch, &blocks);
     if (prc != RTAMD_OK) return prc;
     const int variant = ctx->variant | (ctx->count_work ? 64 : 0);
-    HIPCHK(ctx, hipMemsetAsync(w.queue_head, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
+    if (static_scratch) {
+        // (a kernel, not hipMemsetAsync: captured into a graph, the memset node of the second graph a process builds was seen
+        // not to run when that graph is replayed, and the render kernel then finds the counters where the frame before left them)
+        hipLaunchKernelGGL(rtamd_zero_queue, dim3(1), dim3(256), 0, stream, w.queue_head);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(w.queue_head, 0, RTAMD_QUEUES * RTAMD_QUEUE_STRIDE * sizeof(unsigned long long), stream));
+    }
     // The static entry point records no timing events: its caller may be capturing the stream into a graph, and an event
     // recorded during capture can be neither waited for nor read afterwards (kernel_ms then stays 0).
     const bool time_it = !static_scratch;

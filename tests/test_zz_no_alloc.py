@@ -68,3 +68,39 @@ def test_static_entry_point_shared_by_contexts_and_limits(rt, gpu_ctx):
     strict, _, _ = _rows(rt, other, w, (h, 0, 1, 1), rt.MODE_STRICT, static=False)  # the allocating entry point takes it
     assert np.abs(strict - deep).max() <= 1e-8
     other.close()
+
+
+@pytest.mark.parametrize("name", ["cover", "csg"])
+def test_static_entry_point_can_be_captured_into_a_graph_and_replayed(rt, gpu_ctx, name):
+    """One of the callers the entry point is for: the call is captured into a HIP graph (nothing runs), the graph replayed --
+    the frame of rtamd_render_rows to the bit, every time, in both arithmetic modes, and for the second and third graph
+    of the process as for the first (the work-queue counters are zeroed by a kernel of the library: as a memset node the
+    zeroing was seen to be left out when a process's second graph is replayed).  The counters are read afterwards as ever."""
+    import torch
+    w, h = 200, 120
+    gpu_ctx.upload(rt.Scene.from_sg(sg_path(name)).set_resolution(w, h).flatten())
+    for mode in (rt.MODE_FAST, rt.MODE_STRICT):
+        want = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+        gpu_ctx.render_rows(h, 0, 1, mode, d_rgb=want.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        buf = torch.full((h, w, 3), float("nan"), dtype=torch.float64, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gpu_ctx.render_rows(h, 0, 1, mode, d_rgb=buf.data_ptr(), stream=side.cuda_stream, static=True)  # (a first call outside the capture)
+            side.synchronize()
+            buf.fill_(float("nan"))
+            graph = torch.cuda.CUDAGraph()
+            graph.capture_begin()
+            gpu_ctx.render_rows(h, 0, 1, mode, d_rgb=buf.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, static=True)
+            graph.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(buf).all())  # capturing ran nothing
+        for _ in range(2):
+            buf.fill_(float("nan"))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(buf, want), (name, mode)
+        st = gpu_ctx.stats()  # the counters are read after replays like after any other frame
+        assert st.primary_rays >= w * h
