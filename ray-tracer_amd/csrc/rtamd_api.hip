@@ -38,7 +38,7 @@ struct rtamd_ctx {
     double* d_frames = nullptr;
     size_t frames_levels = 0;
     int64_t total_lanes = 0;
-    int max_blocks[3][128] = {};  // [mode][variant]; [2]: the fast kernels with teams of lanes per pixel
+    int max_blocks[4][128] = {};  // [mode][variant]; [2]: the fast kernels with teams of lanes per pixel, [3]: those at three waves per SIMD
     bool has_levels = false;      // the scene has leaves with DLEAF_LEVELS: strict arithmetic runs the kernels that know them
     bool count_work = false;       // launches use the kernels that count the tests they execute (rtamd_count_work)
     int stat_blocks = 0;
@@ -163,9 +163,11 @@ int rtamd_ctx_create(int device, rtamd_ctx** out) {
         ctx->max_blocks[RTAMD_MODE_FAST][v] = std::max(1, b) * ctx->num_cus;
         if ((e = rtamd_occupancy_teams(v, &b)) != hipSuccess) return bail("occupancy(teams)", e);
         ctx->max_blocks[2][v] = std::max(1, b) * ctx->num_cus;
+        if ((e = rtamd_occupancy_teams3(v, &b)) != hipSuccess) return bail("occupancy(teams3)", e);
+        ctx->max_blocks[3][v] = std::max(1, b) * ctx->num_cus;
     }
     int mb = 0;
-    for (int m = 0; m < 3; m++)
+    for (int m = 0; m < 4; m++)
         for (int c = 0; c < 128; c++) mb = std::max(mb, ctx->max_blocks[m][c]);
     ctx->total_lanes = (int64_t)mb * 256;
     ctx->stat_blocks = mb;
@@ -1337,7 +1339,9 @@ static int launch(rtamd_ctx* ctx, int mode, DWork& w, hipStream_t stream, bool s
     if (time_it && !ctx->skip_ev0) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
     hipError_t e = mode == RTAMD_MODE_STRICT ? (ctx->has_levels ? rtamd_launch_levels(ctx->ds, w, variant, blocks, stream)
                                                                 : rtamd_launch_strict(ctx->ds, w, variant, blocks, stream))
-                   : w.team > 1              ? rtamd_launch_teams(ctx->ds, w, variant & 63, blocks, stream)
+                   : w.team > 1              ? ((w.n_queue + 3) / 4 <= ctx->max_blocks[3][variant & 63]  // every piece gets a wave at 3 waves per SIMD too
+                                                    ? rtamd_launch_teams3(ctx->ds, w, variant & 63, blocks, stream)
+                                                    : rtamd_launch_teams(ctx->ds, w, variant & 63, blocks, stream))
                                              : rtamd_launch_fast(ctx->ds, w, variant, blocks, stream);
     if (e != hipSuccess) return fail(ctx, RTAMD_E_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (time_it && !ctx->skip_ev1) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));

@@ -192,3 +192,6 @@ hipError_t rtamd_occupancy_levels(int variant, int* blocks_per_cu);
 // the fast kernels with teams of lanes per pixel (variant: without the counting bit)
 hipError_t rtamd_launch_teams(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
 hipError_t rtamd_occupancy_teams(int variant, int* blocks_per_cu);
+// ... built for three waves per SIMD (no register spilled to memory), for frames whose every piece of work gets a wave even so
+hipError_t rtamd_launch_teams3(const DScene& s, const DWork& w, int variant, int blocks, hipStream_t stream);
+hipError_t rtamd_occupancy_teams3(int variant, int* blocks_per_cu);

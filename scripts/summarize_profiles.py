@@ -22,7 +22,7 @@ def timed_kernel(name):
     """The kernel the timed frames of bench.py run: the arithmetic mode asked for, not its counting twin (bench.py also
     renders one frame with the counting kernel and, in fast mode, three with the strict one)."""
     base = name.split("(")[0]
-    prefixes = (f"rtamd_render_{mode}_",) + (("rtamd_render_teams_",) if mode == "fast" else ())  # (small frames: the kernels with teams)
+    prefixes = (f"rtamd_render_{mode}_",) + (("rtamd_render_teams_", "rtamd_render_teams3_") if mode == "fast" else ())  # (small frames: the kernels with teams)
     return base.startswith(prefixes) and not base.endswith("_count")
 
 
