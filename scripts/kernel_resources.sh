@@ -1,5 +1,5 @@
 #!/bin/bash
-# Registers, spills and scratch of every render kernel (no GPU needed): scripts/kernel_resources.sh [fast|strict|teams] [extra hipcc flags]
+# Registers, spills and scratch of every render kernel (no GPU needed): scripts/kernel_resources.sh [fast|strict|levels|teams|teams3] [extra hipcc flags]
 mode=${1:-fast}; shift || true
 cd "$(dirname "$0")/../ray-tracer_amd"
 contract=$([ "$mode" = strict ] && echo off || echo fast)
