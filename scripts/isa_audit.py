@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction table of one render kernel, by section of csrc/rtamd_kernel.inc and by instruction class.
 
-    scripts/isa_audit.py [--mode fast|strict|teams] [--kernel rtamd_render_fast_plain_bounds_slab] [--asm file.s] [--loops]
+    scripts/isa_audit.py [--mode fast|strict|levels|teams|teams3] [--kernel rtamd_render_fast_plain_bounds_slab] [--asm file.s] [--loops]
 
 Compiles the kernel source for gfx950 with line tables (no GPU needed), walks the assembly of the one kernel and
 books every instruction under the source line its `.loc` names (the innermost inlined line) and under a class:
@@ -94,7 +94,7 @@ def sections():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="fast", choices=["fast", "strict", "teams"])
+    ap.add_argument("--mode", default="fast", choices=["fast", "strict", "levels", "teams", "teams3"])
     ap.add_argument("--kernel", default=None)
     ap.add_argument("--asm", default=None, help="assembly made with -gline-tables-only (skips the compile)")
     ap.add_argument("--loops", action="store_true")
@@ -104,7 +104,7 @@ def main():
     asm = a.asm
     if asm is None:
         asm = f"/tmp/rtamd_audit_{a.mode}.s"
-        contract = "off" if a.mode == "strict" else "fast"
+        contract = "off" if a.mode in ("strict", "levels") else "fast"
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-ffp-contract={contract}", "-gline-tables-only",
                "--offload-device-only", "-S", os.path.join(ROOT, "ray-tracer_amd", "csrc", f"rtamd_kernels_{a.mode}.hip"), "-o", asm] + a.flags.split()
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)

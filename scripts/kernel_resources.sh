@@ -2,7 +2,7 @@
 # Registers, spills and scratch of every render kernel (no GPU needed): scripts/kernel_resources.sh [fast|strict|levels|teams|teams3] [extra hipcc flags]
 mode=${1:-fast}; shift || true
 cd "$(dirname "$0")/../ray-tracer_amd"
-contract=$([ "$mode" = strict ] && echo off || echo fast)
+contract=$( { [ "$mode" = strict ] || [ "$mode" = levels ]; } && echo off || echo fast)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$contract "$@" -Rpass-analysis=kernel-resource-usage \
     -c csrc/rtamd_kernels_$mode.hip -o /tmp/rtamd_res_$mode.o 2>&1 |
 python3 -c '
