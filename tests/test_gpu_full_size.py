@@ -116,3 +116,18 @@ def test_host_frame_in_chunks_equals_the_frame_rendered_whole(rt, gpu_ctx, name,
         only8 = np.empty((h, w, 3), dtype=np.uint8)  # 8-bit channels alone
         gpu_ctx._chk(rt._gpu.rtamd_render(gpu_ctx._h, mode, None, only8.ctypes.data))
         assert np.array_equal(only8, want8)
+
+
+def test_every_pixel_of_cover_at_3840x2160(rt, oracle, gpu_ctx):
+    """The default benchmark frame, all 8.3 million pixels against the oracle (its mode with cached inverses renders the frame in
+    seconds and gives the bits of the faithful mode, tests/test_oracle.py): strict arithmetic to 1e-14 -- what remains is the last
+    bit of pow -- fast arithmetic to its 1e-8, and not one 8-bit channel different in either."""
+    w, h = 3840, 2160
+    ref, ref8, _ = oracle.OracleScene(sg_path("cover")).render(w, h, threads=16)
+    gpu_ctx.upload(rt.Scene.from_sg(sg_path("cover")).set_resolution(w, h).flatten())
+    for mode, tol in ((rt.MODE_STRICT, 1e-14), (rt.MODE_FAST, 1e-8)):
+        rgb, u8 = gpu_ctx.render(w, h, mode, want_u8=True)
+        worst = float(np.abs(rgb - ref).max())
+        print(f"cover {w}x{h} mode {mode}: max |diff| over {w * h} pixels {worst:.3e}")
+        assert worst <= tol
+        assert np.array_equal(u8, ref8)
